@@ -1,0 +1,48 @@
+"""Build libartemis_synth.so for gfx950 with hipcc (in-tree; cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+SRC = os.path.join(_PKG, "csrc", "synth_kernels.hip")
+INCLUDE = os.path.join(_ROOT, "include")
+LIB_DIR = os.path.join(_PKG, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libartemis_synth.so")
+
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950",
+    "-O3",
+    "-fPIC",
+    "-shared",
+    "-munsafe-fp-atomics",  # fp32 atomicAdd -> one global_atomic_add_f32, no CAS loop
+    "-Wall",
+]
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [SRC, os.path.join(INCLUDE, "artemis_synth.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP kernels + C ABI into artemis_amd/lib/libartemis_synth.so."""
+    if not force and not needs_build():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "hipcc")
+    cmd = [hipcc, *HIPCC_FLAGS, "-I" + INCLUDE, "-o", LIB_PATH, SRC]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stderr)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,803 @@
+// synth_kernels.hip -- ArTEMIS frame-synthesis op for MI355X (gfx950, CDNA4).
+//
+// What it computes (reference: /root/reference/cupy_module/synth.py, kernel text :6-201):
+//   out[n,c,y,x] = sum_{r,s<k} w[n,rk+s,y,x] * B(in[n,c], y+r*d+trunc(a), x+s*d+trunc(b),
+//                                                a-trunc(a), b-trunc(b))
+//   a = offset_y[n,rk+s,y,x], b = offset_x[...], trunc = C (int) cast, B = 2x2 blend with the
+//   four indices clamped to the padded frame.  Backward: gradWeight, gradOffset_y,
+//   gradOffset_x as in the reference's three kernels, fused; gradInput (absent upstream) as the
+//   exact adjoint.
+//
+// Design (DESIGN.md has the numbers): the op is an HBM stream of the 3 x 25 per-pixel planes
+// (300 of 324 B/pixel forward, 600 of 624 B/pixel backward) with a 4-corner x 3-channel gather
+// from a 12 B/pixel frame.  One lane owns one output pixel (64 lanes = 64 consecutive x, so every
+// plane access of a wave is one coalesced 256 B segment) and keeps all channels in registers,
+// so the planes are read once (the reference re-reads them per channel).  The frame tile of a
+// 64 x TH pixel workgroup, extended by the tap footprint and a displacement radius R, is staged
+// once into LDS as float4 {c0,c1,c2,-} texels with the border clamp already applied, so the
+// gathers are ds_read_b128 from one address register with immediate offsets and never touch
+// the vector memory pipe.  Taps displaced beyond R fall back per lane to clamped global loads.
+// No MFMA: there is no dense contraction here.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "artemis_synth.h"
+
+namespace {
+
+// Problem geometry shared by all kernels. Frame row index of tap (r) at output row y with
+// truncated offset ia is  y + oy0 + r*d + ia  (oy0 = ox0 = 0 for the reference layout).
+struct Geom {
+    int N, C, H, W;
+    int k, d;
+    int Hin, Win;
+    int oy0, ox0;
+};
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
+
+// two's-complement wrapping add, as the device's integer add in the reference does
+__device__ __forceinline__ int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
+
+// ------------------------------------------------------------------------------------------
+// Direct path: any k, d, C.  Gathers go through L1/L2.  One lane per (n, y, x).
+// Block (64,4): a wave is 64 consecutive x of one row.  The per-pixel bodies are also the
+// fix-up path of the LDS-staged kernels below.
+// ------------------------------------------------------------------------------------------
+
+struct TapIdx {
+    int bl, tl, br, tr;  // element offsets inside one frame plane
+    float fa, fb;
+};
+
+__device__ __forceinline__ TapIdx tap_index(const Geom &g, float a, float b, int ybase, int xbase)
+{
+    TapIdx t;
+    const int ia = (int)a, ib = (int)b;  // v_cvt_i32_f32: toward zero, saturating, NaN -> 0
+    const int yy = wadd(ybase, ia), xx = wadd(xbase, ib);
+    const int bottom = clampi(yy, 0, g.Hin - 1), top = clampi(wadd(yy, 1), 0, g.Hin - 1);
+    const int left = clampi(xx, 0, g.Win - 1), right = clampi(wadd(xx, 1), 0, g.Win - 1);
+    t.bl = bottom * g.Win + left;
+    t.tl = top * g.Win + left;
+    t.br = bottom * g.Win + right;
+    t.tr = top * g.Win + right;
+    t.fa = a - (float)ia;
+    t.fb = b - (float)ib;
+    return t;
+}
+
+// Forward for one pixel, channels [c0, c0 + CH).  wp/ap/bp point at tap 0 of this pixel,
+// ip at channel c0 of this sample's frame, op at channel c0 of this pixel's output.
+template <int CH>
+__device__ __forceinline__ void fwd_pixel_direct(const float *__restrict__ ip,
+                                                 const float *__restrict__ wp,
+                                                 const float *__restrict__ ap,
+                                                 const float *__restrict__ bp,
+                                                 float *__restrict__ op, const Geom &g, int y, int x)
+{
+    const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
+    float acc[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) acc[c] = 0.f;
+    for (int r = 0; r < g.k; ++r) {
+        for (int s = 0; s < g.k; ++s) {
+            const size_t t = (size_t)(r * g.k + s) * plane;
+            const float wv = wp[t], a = ap[t], b = bp[t];
+            const TapIdx ti = tap_index(g, a, b, y + g.oy0 + r * g.d, x + g.ox0 + s * g.d);
+            const float ga = 1.f - ti.fa, gb = 1.f - ti.fb;
+            const float c00 = ga * gb, c10 = ti.fa * gb, c01 = ga * ti.fb, c11 = ti.fa * ti.fb;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const float *p = ip + (size_t)c * iplane;
+                acc[c] += wv * (p[ti.bl] * c00 + p[ti.tl] * c10 + p[ti.br] * c01 + p[ti.tr] * c11);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) op[(size_t)c * plane] = acc[c];
+}
+
+template <int CH>
+__global__ __launch_bounds__(256) void synth_fwd_direct(const float *__restrict__ in,
+                                                         const float *__restrict__ w,
+                                                         const float *__restrict__ oy,
+                                                         const float *__restrict__ ox,
+                                                         float *__restrict__ out, Geom g, int c0)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    const int n = blockIdx.z;
+    if (x >= g.W || y >= g.H) return;
+    const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
+    const size_t pix = (size_t)y * g.W + x;
+    const size_t tb = (size_t)n * g.k * g.k * plane + pix;
+    fwd_pixel_direct<CH>(in + ((size_t)n * g.C + c0) * iplane, w + tb, oy + tb, ox + tb,
+                         out + ((size_t)n * g.C + c0) * plane + pix, g, y, x);
+}
+
+// Fused gradWeight / gradOffset_y / gradOffset_x for one pixel, all C channels (run-time loop).
+// gwp/goyp/goxp point at tap 0 of this pixel (each may be null), gp at channel 0 of gradOutput.
+__device__ __forceinline__ void bwd_pixel_direct(const float *__restrict__ ip,
+                                                 const float *__restrict__ wp,
+                                                 const float *__restrict__ ap,
+                                                 const float *__restrict__ bp,
+                                                 const float *__restrict__ gp,
+                                                 float *__restrict__ gwp, float *__restrict__ goyp,
+                                                 float *__restrict__ goxp, const Geom &g, int y,
+                                                 int x)
+{
+    const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
+    for (int r = 0; r < g.k; ++r) {
+        for (int s = 0; s < g.k; ++s) {
+            const size_t t = (size_t)(r * g.k + s) * plane;
+            const float a = ap[t], b = bp[t];
+            const TapIdx ti = tap_index(g, a, b, y + g.oy0 + r * g.d, x + g.ox0 + s * g.d);
+            // channel-reduced corner sums: P_q = sum_c delta_c * corner_q(c)
+            float pbl = 0.f, ptl = 0.f, pbr = 0.f, ptr_ = 0.f;
+            for (int c = 0; c < g.C; ++c) {
+                const float dl = gp[(size_t)c * plane];
+                const float *p = ip + (size_t)c * iplane;
+                pbl += dl * p[ti.bl];
+                ptl += dl * p[ti.tl];
+                pbr += dl * p[ti.br];
+                ptr_ += dl * p[ti.tr];
+            }
+            const float fa = ti.fa, fb = ti.fb, ga = 1.f - fa, gb = 1.f - fb;
+            if (gwp) gwp[t] = pbl * (ga * gb) + ptl * (fa * gb) + pbr * (ga * fb) + ptr_ * (fa * fb);
+            if (goyp || goxp) {
+                const float wv = wp[t];
+                if (goyp) goyp[t] = wv * ((ptl - pbl) * gb + (ptr_ - pbr) * fb);
+                if (goxp) goxp[t] = wv * ((pbr - pbl) * ga + (ptr_ - ptl) * fa);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void synth_bwd_direct(const float *__restrict__ in,
+                                                         const float *__restrict__ w,
+                                                         const float *__restrict__ oy,
+                                                         const float *__restrict__ ox,
+                                                         const float *__restrict__ gout,
+                                                         float *__restrict__ gw,
+                                                         float *__restrict__ goy,
+                                                         float *__restrict__ gox, Geom g)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    const int n = blockIdx.z;
+    if (x >= g.W || y >= g.H) return;
+    const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
+    const size_t pix = (size_t)y * g.W + x;
+    const size_t tb = (size_t)n * g.k * g.k * plane + pix;
+    bwd_pixel_direct(in + (size_t)n * g.C * iplane, w + tb, oy + tb, ox + tb,
+                     gout + (size_t)n * g.C * plane + pix, gw ? gw + tb : nullptr,
+                     goy ? goy + tb : nullptr, gox ? gox + tb : nullptr, g, y, x);
+}
+
+// gradInput, fp32 atomics straight to global memory (any k, d, C).  gin must be zeroed.
+__global__ __launch_bounds__(256) void synth_gin_atomic_direct(const float *__restrict__ w,
+                                                                const float *__restrict__ oy,
+                                                                const float *__restrict__ ox,
+                                                                const float *__restrict__ gout,
+                                                                float *__restrict__ gin, Geom g)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    const int n = blockIdx.z;
+    if (x >= g.W || y >= g.H) return;
+    const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
+    const int K = g.k * g.k;
+    const size_t pix = (size_t)y * g.W + x;
+    const size_t tbase = (size_t)n * K * plane + pix;
+    float *op = gin + (size_t)n * g.C * iplane;
+    const float *gp = gout + (size_t)n * g.C * plane + pix;
+    for (int r = 0; r < g.k; ++r) {
+        for (int s = 0; s < g.k; ++s) {
+            const size_t t = tbase + (size_t)(r * g.k + s) * plane;
+            const float wv = w[t], a = oy[t], b = ox[t];
+            const TapIdx ti = tap_index(g, a, b, y + g.oy0 + r * g.d, x + g.ox0 + s * g.d);
+            const float c00 = (1.f - ti.fa) * (1.f - ti.fb), c10 = ti.fa * (1.f - ti.fb);
+            const float c01 = (1.f - ti.fa) * ti.fb, c11 = ti.fa * ti.fb;
+            for (int c = 0; c < g.C; ++c) {
+                const float dw = gp[(size_t)c * plane] * wv;
+                float *p = op + (size_t)c * iplane;
+                atomicAdd(p + ti.bl, dw * c00);
+                atomicAdd(p + ti.tl, dw * c10);
+                atomicAdd(p + ti.br, dw * c01);
+                atomicAdd(p + ti.tr, dw * c11);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Deterministic gradInput: every contribution is rounded to a 64-bit fixed-point integer with
+// one scale for the whole call and added with integer atomics.  Integer addition is
+// associative, so the sums (and the fp32 result) are bit-identical run to run whatever the
+// arrival order, for any offsets.  The scale 2^S is chosen from max|w| * max|gradOutput| so
+// that the worst case (every tap of a plane clamped onto one texel) cannot overflow.
+// Workspace: [0] max|w| bits, [1] max|gout| bits (uint32, atomicMax on non-negative float
+// bits), accumulators (int64, one per gradInput element) from byte 256.
+// ------------------------------------------------------------------------------------------
+
+constexpr size_t kDetHeaderBytes = 256;
+
+__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ v, size_t count,
+                                                      unsigned *__restrict__ slot)
+{
+    unsigned m = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned bits = __float_as_uint(v[i]) & 0x7fffffffu;
+        m = max(m, bits);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(slot, m);
+}
+
+// log2 of the fixed-point scale; a pure function of the two maxima, identical in every lane
+__device__ __forceinline__ int det_scale_log2(const unsigned *hdr, int count_bits)
+{
+    const float mw = __uint_as_float(hdr[0]), mg = __uint_as_float(hdr[1]);
+    float m = 4.f * mw * mg;  // |coef| < 4: (1 +|fa|)(1 + |fb|) with |fa|,|fb| < 1
+    if (!(m > 0.f) || !(m < 3.0e38f)) return 0;
+    int e;
+    frexpf(m, &e);  // m < 2^e
+    return 62 - count_bits - e;
+}
+
+__global__ __launch_bounds__(256) void synth_gin_fixed_direct(const float *__restrict__ w,
+                                                               const float *__restrict__ oy,
+                                                               const float *__restrict__ ox,
+                                                               const float *__restrict__ gout,
+                                                               unsigned char *__restrict__ ws,
+                                                               Geom g, int count_bits)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    const int n = blockIdx.z;
+    if (x >= g.W || y >= g.H) return;
+    const double scale = ldexp(1.0, det_scale_log2((const unsigned *)ws, count_bits));
+    unsigned long long *accum = (unsigned long long *)(ws + kDetHeaderBytes);
+    const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
+    const int K = g.k * g.k;
+    const size_t pix = (size_t)y * g.W + x;
+    const size_t tbase = (size_t)n * K * plane + pix;
+    unsigned long long *op = accum + (size_t)n * g.C * iplane;
+    const float *gp = gout + (size_t)n * g.C * plane + pix;
+    for (int r = 0; r < g.k; ++r) {
+        for (int s = 0; s < g.k; ++s) {
+            const size_t t = tbase + (size_t)(r * g.k + s) * plane;
+            const float wv = w[t], a = oy[t], b = ox[t];
+            const TapIdx ti = tap_index(g, a, b, y + g.oy0 + r * g.d, x + g.ox0 + s * g.d);
+            const float c00 = (1.f - ti.fa) * (1.f - ti.fb), c10 = ti.fa * (1.f - ti.fb);
+            const float c01 = (1.f - ti.fa) * ti.fb, c11 = ti.fa * ti.fb;
+            for (int c = 0; c < g.C; ++c) {
+                const double dw = (double)(gp[(size_t)c * plane] * wv) * scale;
+                unsigned long long *p = op + (size_t)c * iplane;
+                atomicAdd(p + ti.bl, (unsigned long long)__double2ll_rn(dw * (double)c00));
+                atomicAdd(p + ti.tl, (unsigned long long)__double2ll_rn(dw * (double)c10));
+                atomicAdd(p + ti.br, (unsigned long long)__double2ll_rn(dw * (double)c01));
+                atomicAdd(p + ti.tr, (unsigned long long)__double2ll_rn(dw * (double)c11));
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void det_finalize_kernel(const unsigned char *__restrict__ ws,
+                                                            float *__restrict__ gin, size_t count,
+                                                            int count_bits)
+{
+    const double inv = ldexp(1.0, -det_scale_log2((const unsigned *)ws, count_bits));
+    const long long *accum = (const long long *)(ws + kDetHeaderBytes);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+         i += (size_t)gridDim.x * blockDim.x)
+        gin[i] = (float)((double)accum[i] * inv);
+}
+
+// ------------------------------------------------------------------------------------------
+// LDS-staged kernels for k = 5, d = 1, C = 3 (the model's configuration).
+// Workgroup = 256 lanes as (64, 4): tile of 64 x TH output pixels; wave w owns rows w, w+4, ...
+// LDS tile: (TH + 5 + 2R) x (64 + 5 + 2R) float4 texels, texel (ly, lx) = the three channels of
+// frame pixel (clamp(gy0 + ly), clamp(gx0 + lx)): the reference's CLAMP is applied at fill
+// time, so reading (ly, ly+1) x (lx, lx+1) needs no clamp.  A tap is served from LDS when
+// 0 <= ly <= LH-2 and 0 <= lx <= LW-2, i.e. |trunc(offset)| <= R.
+// ------------------------------------------------------------------------------------------
+
+constexpr int kTW = 64;
+
+// Native 4-float vector and its LDS-qualified form.  Tile reads go through an explicit
+// address_space(3) pointer: with a generic pointer hipcc merges the LDS read and the global
+// fallback into one flat_load per dword (select of pointers), which kills the design.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+
+template <int R, int TH>
+struct TileShape {
+    static constexpr int LW = kTW + 5 + 2 * R;
+    static constexpr int LH = TH + 5 + 2 * R;
+};
+
+template <int R, int TH>
+__device__ __forceinline__ void fill_tile(f32x4 *tile, const float *__restrict__ ip, const Geom &g,
+                                          int gy0, int gx0, int tid)
+{
+    constexpr int LW = TileShape<R, TH>::LW, LH = TileShape<R, TH>::LH;
+    const int iplane = g.Hin * g.Win;
+    for (int i = tid; i < LH * LW; i += 256) {
+        const int ly = i / LW, lx = i - ly * LW;
+        const int gy = clampi(gy0 + ly, 0, g.Hin - 1), gx = clampi(gx0 + lx, 0, g.Win - 1);
+        const int o = gy * g.Win + gx;
+        tile[i] = f32x4{ip[o], ip[(size_t)iplane + o], ip[2 * (size_t)iplane + o], 0.f};
+    }
+}
+
+// One tap row (5 taps) of the three streamed planes for one pixel, held in registers.
+struct TapRow {
+    float w[5], a[5], b[5];
+};
+
+// wrow/arow/brow: wave-uniform pointers to (tap 0, row y, x = 0); x: this lane's column.
+// Uniform base + 32-bit lane offset keeps the address math on the scalar unit
+// (global_load_dword v, v_off, s[base]).
+__device__ __forceinline__ void load_tap_row(TapRow &t, const float *__restrict__ wrow,
+                                             const float *__restrict__ arow,
+                                             const float *__restrict__ brow, size_t plane, int r,
+                                             unsigned x)
+{
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const size_t o = (size_t)(r * 5 + s) * plane;
+        t.w[s] = (wrow + o)[x];
+        t.a[s] = (arow + o)[x];
+        t.b[s] = (brow + o)[x];
+    }
+}
+
+struct Corners {
+    f32x4 bl, tl, br, tr;
+};
+
+// The 2x2 x 3-channel footprint of one tap from the staged tile.  The hot loop is branch-free:
+// a footprint outside the tile reads an in-bounds (meaningless) texel and raises `bad`; a lane
+// with `bad` set recomputes its pixel through the direct path after the loop.
+template <int R, int TH>
+__device__ __forceinline__ Corners tile_corners(const lds_f32x4 *tile, int ly, int lx, bool &bad)
+{
+    constexpr int LW = TileShape<R, TH>::LW, LH = TileShape<R, TH>::LH;
+    bad |= (unsigned)ly >= (unsigned)(LH - 1);
+    bad |= (unsigned)lx >= (unsigned)(LW - 1);
+    // 24-bit multiply: exact whenever the footprint is inside; anything else is clamped in-bounds
+    const unsigned idx = min(__umul24((unsigned)ly, (unsigned)LW) + (unsigned)lx,
+                             (unsigned)((LH - 1) * LW - 2));
+    const lds_f32x4 *p = tile + idx;
+    Corners q;
+    q.bl = p[0];
+    q.br = p[1];
+    q.tl = p[LW];
+    q.tr = p[LW + 1];
+    return q;
+}
+
+template <int R, int TH>
+__global__ __launch_bounds__(256, 4) void synth_fwd_tiled(const float *__restrict__ in,
+                                                           const float *__restrict__ w,
+                                                           const float *__restrict__ oy,
+                                                           const float *__restrict__ ox,
+                                                           float *__restrict__ out, Geom g)
+{
+    constexpr int LW = TileShape<R, TH>::LW, LH = TileShape<R, TH>::LH;
+    __shared__ f32x4 tile[LH * LW];
+    const lds_f32x4 *ltile = (const lds_f32x4 *)tile;
+    const int tx0 = blockIdx.x * kTW, ty0 = blockIdx.y * TH, n = blockIdx.z;
+    const int wy = __builtin_amdgcn_readfirstlane(threadIdx.y);  // wave index: uniform
+    const int tid = wy * 64 + threadIdx.x;
+    const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
+    const float *ip = in + (size_t)n * 3 * iplane;
+    const int px = threadIdx.x, x = tx0 + px;
+    const bool active = x < g.W && ty0 + wy < g.H;
+    const size_t nbase = (size_t)n * 25 * plane;
+
+    // first tap row of this lane's first pixel: issued before the tile fill so the stream is
+    // already in flight while the tile is staged
+    TapRow cur;
+    size_t rowoff = nbase + (size_t)(ty0 + wy) * g.W;  // uniform
+    if (active) load_tap_row(cur, w + rowoff, oy + rowoff, ox + rowoff, plane, 0, (unsigned)x);
+
+    fill_tile<R, TH>(tile, ip, g, ty0 + g.oy0 - R, tx0 + g.ox0 - R, tid);
+    __syncthreads();
+    if (!active) return;
+
+#pragma unroll 1
+    for (int py = wy; py < TH; py += 4) {
+        const int y = ty0 + py;
+        const bool more = py + 4 < TH && y + 4 < g.H;  // wave-uniform
+        const float *wrow = w + rowoff, *arow = oy + rowoff, *brow = ox + rowoff;
+        float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
+        bool bad = false;
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            TapRow nxt;
+            if (r < 4) {
+                load_tap_row(nxt, wrow, arow, brow, plane, r + 1, (unsigned)x);
+            } else if (more) {
+                const size_t o = (size_t)4 * g.W;
+                load_tap_row(nxt, wrow + o, arow + o, brow + o, plane, 0, (unsigned)x);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 5; ++s) {
+                const float wv = cur.w[s], a = cur.a[s], b = cur.b[s];
+                const int ia = (int)a, ib = (int)b;
+                const float fa = a - (float)ia, fb = b - (float)ib;
+                const Corners q =
+                    tile_corners<R, TH>(ltile, wadd(py + r + R, ia), wadd(px + s + R, ib), bad);
+                const float ga = 1.f - fa, gb = 1.f - fb;
+                const float c00 = ga * gb, c10 = fa * gb, c01 = ga * fb, c11 = fa * fb;
+                acc0 += wv * (q.bl.x * c00 + q.tl.x * c10 + q.br.x * c01 + q.tr.x * c11);
+                acc1 += wv * (q.bl.y * c00 + q.tl.y * c10 + q.br.y * c01 + q.tr.y * c11);
+                acc2 += wv * (q.bl.z * c00 + q.tl.z * c10 + q.br.z * c01 + q.tr.z * c11);
+            }
+            // Pin this row's arithmetic before the barrier: instruction selection otherwise
+            // floats the (chain-free) FMAs to the end of the unrolled block and keeps every
+            // LDS result of the pixel live.
+            asm volatile("" : "+v"(acc0), "+v"(acc1), "+v"(acc2));
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
+        }
+        // Stored unconditionally (a conditional store lets the optimiser sink the whole
+        // accumulation past the loop); a lane with an out-of-tile tap then overwrites it.
+        float *orow = out + (size_t)n * 3 * plane + (size_t)y * g.W;
+        orow[(unsigned)x] = acc0;
+        (orow + plane)[(unsigned)x] = acc1;
+        (orow + 2 * plane)[(unsigned)x] = acc2;
+        if (bad) fwd_pixel_direct<3>(ip, wrow + x, arow + x, brow + x, orow + x, g, y, x);
+        if (!more) break;
+        rowoff += (size_t)4 * g.W;
+    }
+}
+
+// ALL: the three gradients are all requested (the model's case); the run-time null checks of
+// the general variant would otherwise put 75 scalar branches in the unrolled body.
+template <int R, int TH, bool ALL>
+__global__ __launch_bounds__(256, 4) void synth_bwd_tiled(const float *__restrict__ in,
+                                                           const float *__restrict__ w,
+                                                           const float *__restrict__ oy,
+                                                           const float *__restrict__ ox,
+                                                           const float *__restrict__ gout,
+                                                           float *__restrict__ gw,
+                                                           float *__restrict__ goy,
+                                                           float *__restrict__ gox, Geom g)
+{
+    constexpr int LW = TileShape<R, TH>::LW, LH = TileShape<R, TH>::LH;
+    __shared__ f32x4 tile[LH * LW];
+    const lds_f32x4 *ltile = (const lds_f32x4 *)tile;
+    const int tx0 = blockIdx.x * kTW, ty0 = blockIdx.y * TH, n = blockIdx.z;
+    const int wy = __builtin_amdgcn_readfirstlane(threadIdx.y);  // wave index: uniform
+    const int tid = wy * 64 + threadIdx.x;
+    const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
+    const float *ip = in + (size_t)n * 3 * iplane;
+    const int px = threadIdx.x, x = tx0 + px;
+    const bool active = x < g.W && ty0 + wy < g.H;
+    const size_t nbase = (size_t)n * 25 * plane;
+
+    TapRow cur;
+    size_t rowoff = nbase + (size_t)(ty0 + wy) * g.W;  // uniform
+    if (active) load_tap_row(cur, w + rowoff, oy + rowoff, ox + rowoff, plane, 0, (unsigned)x);
+
+    fill_tile<R, TH>(tile, ip, g, ty0 + g.oy0 - R, tx0 + g.ox0 - R, tid);
+    __syncthreads();
+    if (!active) return;
+
+#pragma unroll 1
+    for (int py = wy; py < TH; py += 4) {
+        const int y = ty0 + py;
+        const bool more = py + 4 < TH && y + 4 < g.H;  // wave-uniform
+        const float *wrow = w + rowoff, *arow = oy + rowoff, *brow = ox + rowoff;
+        const float *grow = gout + (size_t)n * 3 * plane + (size_t)y * g.W;
+        const float d0 = grow[(unsigned)x], d1 = (grow + plane)[(unsigned)x],
+                    d2 = (grow + 2 * plane)[(unsigned)x];
+        bool bad = false;
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            TapRow nxt;
+            if (r < 4) {
+                load_tap_row(nxt, wrow, arow, brow, plane, r + 1, (unsigned)x);
+            } else if (more) {
+                const size_t o = (size_t)4 * g.W;
+                load_tap_row(nxt, wrow + o, arow + o, brow + o, plane, 0, (unsigned)x);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 5; ++s) {
+                const float wv = cur.w[s], a = cur.a[s], b = cur.b[s];
+                const int ia = (int)a, ib = (int)b;
+                const float fa = a - (float)ia, fb = b - (float)ib;
+                const Corners q =
+                    tile_corners<R, TH>(ltile, wadd(py + r + R, ia), wadd(px + s + R, ib), bad);
+                const float pbl = d0 * q.bl.x + d1 * q.bl.y + d2 * q.bl.z;
+                const float ptl = d0 * q.tl.x + d1 * q.tl.y + d2 * q.tl.z;
+                const float pbr = d0 * q.br.x + d1 * q.br.y + d2 * q.br.z;
+                const float ptr_ = d0 * q.tr.x + d1 * q.tr.y + d2 * q.tr.z;
+                const float ga = 1.f - fa, gb = 1.f - fb;
+                const size_t t = rowoff + (size_t)(r * 5 + s) * plane;  // uniform
+                if (ALL || gw)
+                    (gw + t)[(unsigned)x] =
+                        pbl * (ga * gb) + ptl * (fa * gb) + pbr * (ga * fb) + ptr_ * (fa * fb);
+                if (ALL || goy) (goy + t)[(unsigned)x] = wv * ((ptl - pbl) * gb + (ptr_ - pbr) * fb);
+                if (ALL || gox) (gox + t)[(unsigned)x] = wv * ((pbr - pbl) * ga + (ptr_ - ptl) * fa);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
+        }
+        if (bad)
+            bwd_pixel_direct(ip, wrow + x, arow + x, brow + x, grow + x,
+                             gw ? gw + rowoff + x : nullptr, goy ? goy + rowoff + x : nullptr,
+                             gox ? gox + rowoff + x : nullptr, g, y, x);
+        if (!more) break;
+        rowoff += (size_t)4 * g.W;
+    }
+}
+
+__global__ __launch_bounds__(256) void offset_radius_kernel(const float *__restrict__ oy,
+                                                             const float *__restrict__ ox,
+                                                             size_t count, int *__restrict__ out)
+{
+    int m = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int ia = (int)oy[i], ib = (int)ox[i];
+        // |INT_MIN| does not fit: saturate
+        const int aa = ia == INT32_MIN ? INT32_MAX : abs(ia);
+        const int ab = ib == INT32_MIN ? INT32_MAX : abs(ib);
+        m = max(m, max(aa, ab));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
+// ------------------------------------------------------------------------------------------
+// Host side of the C ABI
+// ------------------------------------------------------------------------------------------
+
+thread_local char g_last_error[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int check_launch(const char *what)
+{
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail((int)e, "%s: %s", what, hipGetErrorString(e));
+    return 0;
+}
+
+// 0 ok, 1 invalid, -1 empty problem
+int make_geom(Geom &g, int N, int C, int H, int W, int k, int d)
+{
+    if (N < 0 || C < 0 || H < 0 || W < 0)
+        return fail(hipErrorInvalidValue, "negative dimension N=%d C=%d H=%d W=%d", N, C, H, W);
+    if (k < 1 || d < 1)
+        return fail(hipErrorInvalidValue, "filter size k=%d and dilation d=%d must be >= 1", k, d);
+    if (N > 65535) return fail(hipErrorInvalidValue, "N=%d exceeds 65535 (grid.z)", N);
+    const long long halo = (long long)(k - 1) * d;
+    const long long Hin = H + halo, Win = W + halo;
+    if (halo > (1 << 20) || (long long)H * W >= (1LL << 31) || Hin * Win >= (1LL << 31) ||
+        (long long)k * k >= (1 << 20))
+        return fail(hipErrorInvalidValue,
+                    "plane too large: H=%d W=%d k=%d d=%d (each plane must hold < 2^31 elements)",
+                    H, W, k, d);
+    g.N = N; g.C = C; g.H = H; g.W = W; g.k = k; g.d = d;
+    g.Hin = (int)Hin; g.Win = (int)Win; g.oy0 = 0; g.ox0 = 0;
+    if (N == 0 || C == 0 || H == 0 || W == 0) return -1;
+    return 0;
+}
+
+// tile radii built for the LDS-staged kernels (TH = 16)
+constexpr int kTileTH = 16;
+constexpr int kDefaultRadius = 4;
+
+int pick_radius(int requested)
+{
+    if (requested == ARTEMIS_SYNTH_RADIUS_NONE) return 0;
+    if (requested < 0) requested = kDefaultRadius;
+    if (requested <= 2) return 2;
+    if (requested <= 4) return 4;
+    return 8;
+}
+
+bool tiled_ok(const Geom &g) { return g.k == 5 && g.d == 1 && g.C == 3; }
+
+dim3 pixel_grid(const Geom &g, int rows_per_block)
+{
+    return dim3((unsigned)((g.W + 63) / 64), (unsigned)((g.H + rows_per_block - 1) / rows_per_block),
+                (unsigned)g.N);
+}
+
+template <int R>
+void launch_fwd_tiled(const float *in, const float *w, const float *oy, const float *ox, float *out,
+                      const Geom &g, hipStream_t st)
+{
+    hipLaunchKernelGGL((synth_fwd_tiled<R, kTileTH>), pixel_grid(g, kTileTH), dim3(64, 4), 0, st, in,
+                       w, oy, ox, out, g);
+}
+
+template <int R>
+void launch_bwd_tiled(const float *in, const float *w, const float *oy, const float *ox,
+                      const float *gout, float *gw, float *goy, float *gox, const Geom &g,
+                      hipStream_t st)
+{
+    if (gw && goy && gox)
+        hipLaunchKernelGGL((synth_bwd_tiled<R, kTileTH, true>), pixel_grid(g, kTileTH), dim3(64, 4), 0,
+                           st, in, w, oy, ox, gout, gw, goy, gox, g);
+    else
+        hipLaunchKernelGGL((synth_bwd_tiled<R, kTileTH, false>), pixel_grid(g, kTileTH), dim3(64, 4), 0,
+                           st, in, w, oy, ox, gout, gw, goy, gox, g);
+}
+
+int count_bits_for(const Geom &g)
+{
+    // contributions that can land on one gradInput element: every tap corner of its plane
+    unsigned long long cnt = (unsigned long long)g.H * g.W * g.k * g.k * 4ull;
+    int bits = 1;
+    while ((1ull << bits) < cnt && bits < 60) ++bits;
+    return bits;
+}
+
+int reduce_blocks(size_t count)
+{
+    const size_t b = (count + 255) / 256;
+    return (int)(b < 2048 ? (b ? b : 1) : 2048);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *artemis_synth_version(void)
+{
+    return "artemis_synth abi " "1" " gfx950 hip (fwd, fused bwd, grad_input atomic+deterministic)";
+}
+
+const char *artemis_synth_last_error(void) { return g_last_error; }
+
+int artemis_synth_forward(const float *input, const float *weight, const float *offset_y,
+                          const float *offset_x, float *output, int N, int C, int H, int W, int k,
+                          int d, int tile_radius, void *stream)
+{
+    Geom g;
+    const int rc = make_geom(g, N, C, H, W, k, d);
+    if (rc > 0) return rc;
+    if (rc < 0) return 0;
+    if (!input || !weight || !offset_y || !offset_x || !output)
+        return fail(hipErrorInvalidValue, "artemis_synth_forward: NULL tensor pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int R = tiled_ok(g) ? pick_radius(tile_radius) : 0;
+    switch (R) {
+    case 2: launch_fwd_tiled<2>(input, weight, offset_y, offset_x, output, g, st); break;
+    case 4: launch_fwd_tiled<4>(input, weight, offset_y, offset_x, output, g, st); break;
+    case 8: launch_fwd_tiled<8>(input, weight, offset_y, offset_x, output, g, st); break;
+    default:
+        for (int c0 = 0; c0 < C; c0 += 4) {
+            const int ch = C - c0 < 4 ? C - c0 : 4;
+            const dim3 grid = pixel_grid(g, 4), block(64, 4);
+            switch (ch) {
+            case 1: hipLaunchKernelGGL(synth_fwd_direct<1>, grid, block, 0, st, input, weight, offset_y, offset_x, output, g, c0); break;
+            case 2: hipLaunchKernelGGL(synth_fwd_direct<2>, grid, block, 0, st, input, weight, offset_y, offset_x, output, g, c0); break;
+            case 3: hipLaunchKernelGGL(synth_fwd_direct<3>, grid, block, 0, st, input, weight, offset_y, offset_x, output, g, c0); break;
+            default: hipLaunchKernelGGL(synth_fwd_direct<4>, grid, block, 0, st, input, weight, offset_y, offset_x, output, g, c0); break;
+            }
+        }
+    }
+    return check_launch("artemis_synth_forward");
+}
+
+size_t artemis_synth_backward_workspace_bytes(int N, int C, int H, int W, int k, int d,
+                                              int gin_mode)
+{
+    if (gin_mode != ARTEMIS_SYNTH_GIN_DETERMINISTIC) return 0;
+    Geom g;
+    if (make_geom(g, N, C, H, W, k, d) != 0) return 0;
+    return kDetHeaderBytes + (size_t)N * C * g.Hin * g.Win * sizeof(long long);
+}
+
+int artemis_synth_backward(const float *input, const float *weight, const float *offset_y,
+                           const float *offset_x, const float *grad_output, float *grad_input,
+                           float *grad_weight, float *grad_offset_y, float *grad_offset_x, int N,
+                           int C, int H, int W, int k, int d, int gin_mode, int tile_radius,
+                           void *workspace, size_t workspace_bytes, void *stream)
+{
+    Geom g;
+    const int rc = make_geom(g, N, C, H, W, k, d);
+    if (rc > 0) return rc;
+    if (gin_mode != ARTEMIS_SYNTH_GIN_ATOMIC && gin_mode != ARTEMIS_SYNTH_GIN_DETERMINISTIC)
+        return fail(hipErrorInvalidValue, "artemis_synth_backward: unknown gin_mode %d", gin_mode);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t gin_count = (size_t)N * C * g.Hin * g.Win;
+    if (rc < 0) {
+        // no output pixels: gradInput (which may still have elements) is all zero
+        if (grad_input && gin_count) {
+            const hipError_t e = hipMemsetAsync(grad_input, 0, gin_count * sizeof(float), st);
+            if (e != hipSuccess) return fail((int)e, "hipMemsetAsync: %s", hipGetErrorString(e));
+        }
+        return 0;
+    }
+    if (!input || !weight || !offset_y || !offset_x || !grad_output)
+        return fail(hipErrorInvalidValue, "artemis_synth_backward: NULL tensor pointer");
+
+    if (grad_weight || grad_offset_y || grad_offset_x) {
+        const int R = tiled_ok(g) ? pick_radius(tile_radius) : 0;
+        switch (R) {
+        case 2: launch_bwd_tiled<2>(input, weight, offset_y, offset_x, grad_output, grad_weight, grad_offset_y, grad_offset_x, g, st); break;
+        case 4: launch_bwd_tiled<4>(input, weight, offset_y, offset_x, grad_output, grad_weight, grad_offset_y, grad_offset_x, g, st); break;
+        case 8: launch_bwd_tiled<8>(input, weight, offset_y, offset_x, grad_output, grad_weight, grad_offset_y, grad_offset_x, g, st); break;
+        default:
+            hipLaunchKernelGGL(synth_bwd_direct, pixel_grid(g, 4), dim3(64, 4), 0, st, input, weight,
+                               offset_y, offset_x, grad_output, grad_weight, grad_offset_y,
+                               grad_offset_x, g);
+        }
+        const int e = check_launch("artemis_synth_backward (taps)");
+        if (e) return e;
+    }
+
+    if (grad_input) {
+        if (gin_mode == ARTEMIS_SYNTH_GIN_ATOMIC) {
+            hipError_t e = hipMemsetAsync(grad_input, 0, gin_count * sizeof(float), st);
+            if (e != hipSuccess) return fail((int)e, "hipMemsetAsync: %s", hipGetErrorString(e));
+            hipLaunchKernelGGL(synth_gin_atomic_direct, pixel_grid(g, 4), dim3(64, 4), 0, st, weight,
+                               offset_y, offset_x, grad_output, grad_input, g);
+        } else {
+            const size_t need = kDetHeaderBytes + gin_count * sizeof(long long);
+            if (!workspace || workspace_bytes < need)
+                return fail(hipErrorInvalidValue,
+                            "artemis_synth_backward: deterministic grad_input needs %zu workspace "
+                            "bytes, got %zu", need, workspace ? workspace_bytes : (size_t)0);
+            if (((uintptr_t)workspace & 15) != 0)
+                return fail(hipErrorInvalidValue, "artemis_synth_backward: workspace not 16-byte aligned");
+            unsigned char *ws = (unsigned char *)workspace;
+            hipError_t e = hipMemsetAsync(ws, 0, need, st);
+            if (e != hipSuccess) return fail((int)e, "hipMemsetAsync: %s", hipGetErrorString(e));
+            const size_t wcount = (size_t)N * k * k * H * W, gcount = (size_t)N * C * H * W;
+            hipLaunchKernelGGL(absmax_kernel, dim3(reduce_blocks(wcount)), dim3(256), 0, st, weight,
+                               wcount, (unsigned *)ws);
+            hipLaunchKernelGGL(absmax_kernel, dim3(reduce_blocks(gcount)), dim3(256), 0, st,
+                               grad_output, gcount, (unsigned *)ws + 1);
+            const int bits = count_bits_for(g);
+            hipLaunchKernelGGL(synth_gin_fixed_direct, pixel_grid(g, 4), dim3(64, 4), 0, st, weight,
+                               offset_y, offset_x, grad_output, ws, g, bits);
+            hipLaunchKernelGGL(det_finalize_kernel, dim3(reduce_blocks(gin_count)), dim3(256), 0, st,
+                               ws, grad_input, gin_count, bits);
+        }
+        const int e2 = check_launch("artemis_synth_backward (grad_input)");
+        if (e2) return e2;
+    }
+    return 0;
+}
+
+int artemis_synth_offset_radius(const float *offset_y, const float *offset_x, size_t count,
+                                int *out_radius, void *stream)
+{
+    if (!out_radius) return fail(hipErrorInvalidValue, "artemis_synth_offset_radius: NULL out_radius");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(out_radius, 0, sizeof(int), st);
+    if (e != hipSuccess) return fail((int)e, "hipMemsetAsync: %s", hipGetErrorString(e));
+    if (count == 0) return 0;
+    if (!offset_y || !offset_x)
+        return fail(hipErrorInvalidValue, "artemis_synth_offset_radius: NULL tensor pointer");
+    hipLaunchKernelGGL(offset_radius_kernel, dim3(reduce_blocks(count)), dim3(256), 0, st, offset_y,
+                       offset_x, count, out_radius);
+    return check_launch("artemis_synth_offset_radius");
+}
+
+}  // extern "C"

@@ -1,0 +1,180 @@
+"""FunctionSynth: the ArTEMIS frame-synthesis op on MI355X, same operator interface as the
+reference's ``cupy_module/synth.py`` (paths relative to /root/reference).
+
+Reference interface mirrored here (``cupy_module/synth.py:263-391``)::
+
+    FunctionSynth.apply(input, weight, offset_y, offset_x, dilation) -> output
+    forward(context, input, weight, offset_y, offset_x, dilation)
+    backward(context, gradOutput) -> (gradInput, gradWeight, gradOffset_y, gradOffset_x, None)
+
+called from ``model/chrono_synth.py:66-67,125-126``.  Same argument meaning, same asserts
+(shape relation ``:277-278``, contiguity ``:280-283,331``), same ``NotImplementedError`` for CPU
+tensors (``:310-311,388-389``).  The work is done by hand-written gfx950 kernels behind the C ABI
+in ``include/artemis_synth.h``; torch only owns the memory and the stream.
+
+Deliberate differences from the reference, all supersets:
+
+* ``gradInput`` is the true adjoint when ``input.requires_grad`` (the reference returns unfilled
+  zeros, ``:333,391``).  Accumulation is fp32 atomics, or bit-reproducible when
+  ``options.deterministic`` or ``torch.use_deterministic_algorithms(True)`` is set.
+* ``gradOffset_x`` is gated on ``needs_input_grad[3]`` (the reference tests index 2, ``:336``) and
+  any subset of the three tap gradients may be unneeded (the reference dereferences ``None``,
+  ``:343,358,374``).
+* One fused backward kernel instead of three launches; tensors larger than 2^31 elements work.
+"""
+from __future__ import annotations
+
+import contextlib
+import math
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+
+
+@dataclass
+class SynthOptions:
+    #: displacement radius (whole pixels) served from the LDS-staged frame tile;
+    #: -1 = library default, 0 = no LDS staging (direct gathers).  Any value is correct for any
+    #: offsets: taps displaced farther are recomputed through the direct path.
+    tile_radius: int = _lib.RADIUS_DEFAULT
+    #: bit-reproducible gradInput (fixed-point integer accumulation) instead of fp32 atomics
+    deterministic: bool = False
+
+
+options = SynthOptions()
+
+
+@contextlib.contextmanager
+def synth_options(**kw):
+    """Temporarily override fields of :data:`options`."""
+    old = {k: getattr(options, k) for k in kw}
+    try:
+        for k, v in kw.items():
+            setattr(options, k, v)
+        yield options
+    finally:
+        for k, v in old.items():
+            setattr(options, k, v)
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _dims(input, weight, dilation):
+    # cupy_module/synth.py:269-278 (forward) and :320-329 (backward)
+    intSample = input.size(0)
+    intInputDepth = input.size(1)
+    intInputHeight = input.size(2)
+    intInputWidth = input.size(3)
+    intFilterSize = int(math.sqrt(weight.size(1)))
+    intOutputHeight = weight.size(2)
+    intOutputWidth = weight.size(3)
+    assert intFilterSize * intFilterSize == weight.size(1), "weight.size(1) must be a square"
+    assert (intInputHeight - ((intFilterSize - 1) * dilation + 1) == intOutputHeight - 1)
+    assert (intInputWidth - ((intFilterSize - 1) * dilation + 1) == intOutputWidth - 1)
+    return (intSample, intInputDepth, intOutputHeight, intOutputWidth, intFilterSize,
+            intInputHeight, intInputWidth)
+
+
+def _check_operands(input, weight, offset_y, offset_x):
+    for name, t in (("input", input), ("weight", weight), ("offset_y", offset_y),
+                    ("offset_x", offset_x)):
+        if t.dim() != 4:
+            raise ValueError(f"{name} must be 4-D NCHW, got {tuple(t.shape)}")
+        if t.dtype != torch.float32:
+            raise TypeError(f"{name} must be float32 (the reference is fp32 only), got {t.dtype}")
+        if t.device != input.device:
+            raise ValueError(f"{name} is on {t.device}, input on {input.device}")
+    if weight.shape != offset_y.shape or weight.shape != offset_x.shape:
+        raise ValueError("weight, offset_y and offset_x must have the same shape")
+    if weight.size(0) != input.size(0):
+        raise ValueError("weight and input batch sizes differ")
+
+
+class FunctionSynth(torch.autograd.Function):
+    @staticmethod
+    def forward(context, input, weight, offset_y, offset_x, dilation):
+        context.save_for_backward(input, weight, offset_y, offset_x)
+        context.dilation = dilation
+
+        _check_operands(input, weight, offset_y, offset_x)
+        N, C, H, W, k, _, _ = _dims(input, weight, dilation)
+
+        assert (input.is_contiguous() == True)
+        assert (weight.is_contiguous() == True)
+        assert (offset_y.is_contiguous() == True)
+        assert (offset_x.is_contiguous() == True)
+
+        if not input.is_cuda:
+            raise NotImplementedError()
+
+        lib = _lib.load()
+        with torch.cuda.device(input.device):
+            # the kernel writes every element: no need for the reference's new_zeros (:285)
+            output = input.new_empty(N, C, H, W)
+            stream = torch.cuda.current_stream().cuda_stream
+            _lib.check(lib.artemis_synth_forward(
+                _ptr(input), _ptr(weight), _ptr(offset_y), _ptr(offset_x), _ptr(output),
+                N, C, H, W, k, int(dilation), int(options.tile_radius), stream),
+                "artemis_synth_forward")
+        return output
+
+    @staticmethod
+    def backward(context, gradOutput):
+        input, weight, offset_y, offset_x = context.saved_tensors
+        dilation = context.dilation
+        N, C, H, W, k, Hin, Win = _dims(input, weight, dilation)
+
+        assert (gradOutput.is_contiguous() == True)
+        if not input.is_cuda:
+            raise NotImplementedError()
+        if gradOutput.dtype != torch.float32 or tuple(gradOutput.shape) != (N, C, H, W):
+            raise ValueError("gradOutput must be float32 of the forward output's shape")
+
+        need = context.needs_input_grad
+        lib = _lib.load()
+        with torch.cuda.device(input.device):
+            gradInput = input.new_empty(N, C, Hin, Win) if need[0] else None
+            gradWeight = input.new_empty(N, k * k, H, W) if need[1] else None
+            gradOffset_y = input.new_empty(N, k * k, H, W) if need[2] else None
+            gradOffset_x = input.new_empty(N, k * k, H, W) if need[3] else None
+
+            deterministic = options.deterministic or torch.are_deterministic_algorithms_enabled()
+            mode = _lib.GIN_DETERMINISTIC if deterministic else _lib.GIN_ATOMIC
+            workspace, ws_bytes = None, 0
+            if need[0] and deterministic:
+                ws_bytes = lib.artemis_synth_backward_workspace_bytes(
+                    N, C, H, W, k, int(dilation), mode)
+                workspace = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=input.device)
+            stream = torch.cuda.current_stream().cuda_stream
+            if any(need[:4]):
+                _lib.check(lib.artemis_synth_backward(
+                    _ptr(input), _ptr(weight), _ptr(offset_y), _ptr(offset_x), _ptr(gradOutput),
+                    _ptr(gradInput), _ptr(gradWeight), _ptr(gradOffset_y), _ptr(gradOffset_x),
+                    N, C, H, W, k, int(dilation), mode, int(options.tile_radius),
+                    _ptr(workspace), ws_bytes, stream), "artemis_synth_backward")
+        return gradInput, gradWeight, gradOffset_y, gradOffset_x, None
+
+
+def synth(input, weight, offset_y, offset_x, dilation=1):
+    """Functional form of ``FunctionSynth.apply``."""
+    return FunctionSynth.apply(input, weight, offset_y, offset_x, dilation)
+
+
+def offset_radius(offset_y, offset_x) -> torch.Tensor:
+    """max |trunc(offset)| over both tensors as a 0-d int32 device tensor (no host sync): the
+    ``tile_radius`` that would serve every tap from LDS."""
+    if not offset_y.is_cuda:
+        raise NotImplementedError()
+    assert offset_y.is_contiguous() and offset_x.is_contiguous()
+    assert offset_y.shape == offset_x.shape and offset_y.dtype == torch.float32
+    lib = _lib.load()
+    with torch.cuda.device(offset_y.device):
+        out = torch.empty((), dtype=torch.int32, device=offset_y.device)
+        _lib.check(lib.artemis_synth_offset_radius(
+            _ptr(offset_y), _ptr(offset_x), offset_y.numel(), _ptr(out),
+            torch.cuda.current_stream().cuda_stream), "artemis_synth_offset_radius")
+    return out

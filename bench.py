@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""Headline benchmark: synthesized Mpix/s, forward + backward, 4 context frames at 1080p
+(BASELINE.json `metric`), on N GPUs of one node.
+
+A *step* is one pass of the hot path over one batch of synthetic operands: for each of the 4
+context frames one `artemis_synth_forward`, then for each frame one `artemis_synth_backward`
+(gradWeight + gradOffset_y + gradOffset_x; the frames need no gradient in ArTEMIS,
+model/chrono_synth.py:120-126) -- what one ChronoSynth head does per training step for
+`batch` samples of 1080 x 1920.  A *synthesized pixel* is one (n, y, x) of that head
+(SURVEY.md 8d).  Operands are resident in HBM before the timed region; the kernels are called
+through the C ABI on torch's current stream with preallocated outputs.
+
+Multi-GPU: the op shards by batch x timestep with no data-path collective (every output element
+depends only on its own sample, cupy_module/synth.py:19), so every rank runs the same per-GPU
+workload on its own shard (weak scaling) and `value` = pixels of all ranks / max-over-ranks time.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from artemis_amd import _lib  # noqa: E402
+
+H, W, C, K_TAPS, FRAMES = 1080, 1920, 3, 25, 4
+PAD = 2
+# algorithmic (compulsory) bytes per pixel per frame, fp32: SURVEY.md 8d / DESIGN.md
+FWD_BYTES = 3 * K_TAPS * 4 + C * 4 + C * 4 * (H + 2 * PAD) * (W + 2 * PAD) / (H * W)
+BWD_BYTES = 3 * K_TAPS * 4 + 3 * K_TAPS * 4 + C * 4 + C * 4 * (H + 2 * PAD) * (W + 2 * PAD) / (H * W)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def make_frames(batch, sigma, device, seed):
+    """Synthetic operands per SURVEY.md 8d: frames rand in [0,1] replication-padded by 2, weights
+    softmax over 25 N(0,1) logits, offsets N(0, sigma^2), gradOutput randn."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    frames = []
+    for _ in range(FRAMES):
+        frame = torch.rand(batch, C, H, W, device=device, generator=g)
+        inp = torch.nn.functional.pad(frame, (PAD,) * 4, mode="replicate").contiguous()
+        w = torch.softmax(torch.randn(batch, K_TAPS, H, W, device=device, generator=g), 1)
+        oy = torch.randn(batch, K_TAPS, H, W, device=device, generator=g) * sigma
+        ox = torch.randn(batch, K_TAPS, H, W, device=device, generator=g) * sigma
+        gout = torch.randn(batch, C, H, W, device=device, generator=g)
+        out = torch.empty(batch, C, H, W, device=device)
+        gw, ga, gb = (torch.empty(batch, K_TAPS, H, W, device=device) for _ in range(3))
+        frames.append(dict(inp=inp, w=w, oy=oy, ox=ox, gout=gout, out=out, gw=gw, ga=ga, gb=gb))
+    return frames
+
+
+def cpu_baseline(threads, sigma):
+    """The oracle's C restatement (kind "port": the reference has no CPU path and cannot be
+    built here) timed on the host cores for one full step of the same workload at batch 1."""
+    import numpy as np
+    from oracle import synth_oracle as so
+    so.set_threads(threads)
+    rng = np.random.default_rng(103)
+    t_total = 0.0
+    shape = (1, K_TAPS, H, W)
+    for _ in range(FRAMES):
+        inp = rng.random((1, C, H + 2 * PAD, W + 2 * PAD), dtype=np.float32)
+        logits = rng.standard_normal(shape, dtype=np.float32)
+        e = np.exp(logits)
+        w = (e / e.sum(1, keepdims=True)).astype(np.float32)
+        oy = rng.standard_normal(shape, dtype=np.float32) * np.float32(sigma)
+        ox = rng.standard_normal(shape, dtype=np.float32) * np.float32(sigma)
+        gout = rng.standard_normal((1, C, H, W), dtype=np.float32)
+        t0 = time.perf_counter()
+        so.forward(inp, w, oy, ox, 1)
+        so.grad_weight(gout, inp, w, oy, ox, 1)
+        so.grad_alpha(gout, inp, w, oy, ox, 1)
+        so.grad_beta(gout, inp, w, oy, ox, 1)
+        t_total += time.perf_counter() - t0
+    return {
+        "value": H * W / 1e6 / t_total,
+        "unit": "Mpix/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"1 step = {FRAMES} frames x 1080x1920, batch 1, fwd + gradWeight/Alpha/Beta, "
+                  f"oracle/synth_oracle.c (gcc -O2, OpenMP, {threads} threads), {t_total:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1, help="samples per GPU (1080p each)")
+    ap.add_argument("--sigma", type=float, default=1.0, help="offset std in pixels (headline: 1)")
+    ap.add_argument("--radius", type=int, default=_lib.RADIUS_DEFAULT)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, host cpus)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    lib = _lib.load()  # raises if the HIP library is missing: there is no fallback
+    frames = make_frames(args.batch, args.sigma, device, seed=103 + rank)
+    stream = torch.cuda.current_stream().cuda_stream
+    B = args.batch
+
+    def fwd(f):
+        _lib.check(lib.artemis_synth_forward(
+            f["inp"].data_ptr(), f["w"].data_ptr(), f["oy"].data_ptr(), f["ox"].data_ptr(),
+            f["out"].data_ptr(), B, C, H, W, 5, 1, args.radius, stream), "forward")
+
+    def bwd(f):
+        _lib.check(lib.artemis_synth_backward(
+            f["inp"].data_ptr(), f["w"].data_ptr(), f["oy"].data_ptr(), f["ox"].data_ptr(),
+            f["gout"].data_ptr(), None, f["gw"].data_ptr(), f["ga"].data_ptr(),
+            f["gb"].data_ptr(), B, C, H, W, 5, 1, _lib.GIN_ATOMIC, args.radius, None, 0, stream),
+            "backward")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    bwd_events, fwd_events = [], []
+
+    def step(record):
+        for f in frames:
+            if record:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fwd(f)
+                e1.record()
+                fwd_events.append((e0, e1))
+            else:
+                fwd(f)
+        for f in frames:
+            if record:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                bwd(f)
+                e1.record()
+                bwd_events.append((e0, e1))
+            else:
+                bwd(f)
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+
+    ms = (t1 - t0) * 1e3 / args.steps
+    if world > 1:
+        tt = torch.tensor([ms], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ms = float(tt.item())
+
+    if rank == 0:
+        pix_per_step = world * B * H * W
+        value = pix_per_step / (ms * 1e-3) / 1e6
+        bwd_ms = sum(a.elapsed_time(b) for a, b in bwd_events) / len(bwd_events)
+        fwd_ms = sum(a.elapsed_time(b) for a, b in fwd_events) / len(fwd_events)
+        bwd_gbs = BWD_BYTES * B * H * W / (bwd_ms * 1e-3) / 1e9
+        fwd_gbs = FWD_BYTES * B * H * W / (fwd_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("synth_bwd_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "synthesized Mpix/s fwd+bwd (4 frames, 1080p)",
+            "value": round(value, 2),
+            "unit": "Mpix/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "synth op fwd+bwd (gradWeight, gradOffset_y, gradOffset_x), 4 frames x "
+                            "1080x1920, k=5 d=1 C=3, fp32",
+                "batch_per_gpu": B,
+                "offset_sigma_px": args.sigma,
+                "tile_radius": args.radius,
+                "sharding": "batch x timestep, no collective",
+                "hbm_frac_of_8TBps_whole_step": round(
+                    value * 1e6 * (FWD_BYTES + BWD_BYTES) * FRAMES / world / 1e9 / HBM_PEAK_GBS, 4),
+                "fwd_kernel_ms": round(fwd_ms, 4),
+                "fwd_kernel_GBps": round(fwd_gbs, 1),
+            },
+            "roofline": {
+                "kernel": "synth_bwd_tiled (fused gradWeight/gradOffset_y/gradOffset_x)",
+                "bound": "hbm",
+                "achieved": round(bwd_gbs, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(bwd_gbs / HBM_PEAK_GBS, 4),
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": round(BWD_BYTES * B * H * W),
+                "avg_launch_ms": round(bwd_ms, 4),
+            },
+        }
+        if not args.no_cpu_baseline:
+            threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+            line["cpu_baseline"] = cpu_baseline(threads, args.sigma)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

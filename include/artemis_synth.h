@@ -1,0 +1,106 @@
+/*
+ * artemis_synth.h -- C ABI of libartemis_synth.so: ArTEMIS's frame-synthesis op (per-pixel
+ * adaptive deformable convolution) as hand-written CDNA4 (gfx950) HIP kernels.
+ *
+ * This is the drop-in boundary for the one hot path this repository replaces.  In the reference
+ * (paths relative to /root/reference) the boundary is the raw CuPy launch
+ *     cupy_launch(name, cupy_kernel(name, k, d, {...}))(grid, block, args=[n, ptrs...], stream)
+ * at cupy_module/synth.py:298-309 (forward) and :343-387 (backward), issued from
+ * FunctionSynth.forward / .backward (:263-391).  Each entry point below states which of those
+ * it replaces.  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *  - plain C: pointers are DEVICE pointers on the current HIP device, sizes are ints, no torch
+ *    or C++ types cross the boundary.
+ *  - tensors are contiguous NCHW fp32 (the reference asserts contiguity, :280-283, :331):
+ *        input     (N, C, H + (k-1)*d, W + (k-1)*d)     the replication-padded frame
+ *        weight    (N, k*k, H, W)                        offset_y / offset_x likewise
+ *        output    (N, C, H, W)                          grad_output likewise
+ *  - the library never allocates, frees or retains caller memory; it only enqueues work on
+ *    `stream` (a hipStream_t; NULL = the null stream) and returns.  The reference launches on
+ *    torch.cuda.current_stream() (:294-295, :339-340); the caller passes that handle.
+ *  - every function returns 0 on success or a hipError_t value (> 0); arguments that fail
+ *    validation give hipErrorInvalidValue (1).  artemis_synth_last_error() returns a
+ *    thread-local description of the last failure on the calling thread.  No exception crosses
+ *    the boundary.
+ *  - entry points are reentrant and hold no mutable global state: forward is called from the
+ *    user's thread, backward from PyTorch's autograd thread.
+ *  - empty problems (N, H or W equal to 0) are a successful no-op.
+ *  - limits: one (H*W) plane and one padded frame plane must each hold fewer than 2^31
+ *    elements; N <= 65535; total element counts are 64-bit (the reference's `const int n`
+ *    limit, :8, is not inherited).
+ */
+#ifndef ARTEMIS_SYNTH_H
+#define ARTEMIS_SYNTH_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ARTEMIS_SYNTH_ABI_VERSION 1
+
+/* tile_radius: how far (in whole pixels) a tap may be displaced by its offsets and still be
+ * served from the LDS-staged frame tile; larger displacements take a slower clamped global
+ * gather, so every value is correct for any offset.  > 0 picks the smallest built tile radius
+ * that covers it; ARTEMIS_SYNTH_RADIUS_DEFAULT lets the library choose; ARTEMIS_SYNTH_RADIUS_NONE
+ * disables LDS staging (direct gathers through L1/L2).  Only k = 5, d = 1, C = 3 (the model's
+ * configuration: config.py:26-27) has an LDS-staged kernel; other shapes always gather
+ * directly. */
+#define ARTEMIS_SYNTH_RADIUS_DEFAULT (-1)
+#define ARTEMIS_SYNTH_RADIUS_NONE 0
+
+/* grad_input accumulation mode of artemis_synth_backward */
+#define ARTEMIS_SYNTH_GIN_ATOMIC 0        /* fp32 atomics; run-to-run last-bit differences */
+#define ARTEMIS_SYNTH_GIN_DETERMINISTIC 1 /* bit-exact run to run; needs the workspace */
+
+/* Replaces the kernel_Synth_updateOutput launch, cupy_module/synth.py:297-309
+ * (kernel text :6-52; called from FunctionSynth.forward :265-313).
+ *   output[n,c,y,x] = sum over taps (r,s) of weight[n,r*k+s,y,x] * bilinear(input[n,c], ...)
+ * with truncation toward zero of the offsets and index clamping exactly as the reference. */
+int artemis_synth_forward(const float *input, const float *weight, const float *offset_y,
+                          const float *offset_x, float *output, int N, int C, int H, int W, int k,
+                          int d, int tile_radius, void *stream);
+
+/* Replaces the three launches kernel_Synth_updateGradWeight / updateGradAlpha / updateGradBeta,
+ * cupy_module/synth.py:343-387 (kernel text :54-201; called from FunctionSynth.backward
+ * :316-391), fused into one pass.  Each of grad_input, grad_weight, grad_offset_y,
+ * grad_offset_x may be NULL (that gradient is not needed: context.needs_input_grad, :333-336);
+ * at least the non-NULL ones are fully overwritten.
+ *
+ * grad_input has no counterpart in the reference, which returns unfilled zeros (:333, :391);
+ * here it is the true adjoint of the forward w.r.t. `input`.  gin_mode selects fp32 atomics or
+ * the deterministic accumulation; the latter needs `workspace` of at least
+ * artemis_synth_backward_workspace_bytes(...) bytes (device memory, 16-byte aligned, contents
+ * undefined on entry and exit).  `workspace` may be NULL otherwise.
+ * Channels: the reference hard-codes 3 (:75, :125, :175); any C >= 1 is summed here. */
+int artemis_synth_backward(const float *input, const float *weight, const float *offset_y,
+                           const float *offset_x, const float *grad_output, float *grad_input,
+                           float *grad_weight, float *grad_offset_y, float *grad_offset_x, int N,
+                           int C, int H, int W, int k, int d, int gin_mode, int tile_radius,
+                           void *workspace, size_t workspace_bytes, void *stream);
+
+/* Bytes of workspace artemis_synth_backward needs for these dimensions and gin_mode when
+ * grad_input is requested (0 when none is needed).  Host-only arithmetic; no reference
+ * counterpart (the reference has no grad_input kernel). */
+size_t artemis_synth_backward_workspace_bytes(int N, int C, int H, int W, int k, int d,
+                                              int gin_mode);
+
+/* max over both offset tensors of |trunc(offset)| as one int32 written to *out_radius (device
+ * memory), enqueued on `stream`: the tile_radius that would serve every tap from LDS.  `count`
+ * = elements per tensor.  Helper for callers that want to size tile_radius; no reference
+ * counterpart. */
+int artemis_synth_offset_radius(const float *offset_y, const float *offset_x, size_t count,
+                                int *out_radius, void *stream);
+
+/* Library identification: "artemis_synth <abi> gfx950 ..." (static storage). */
+const char *artemis_synth_version(void);
+
+/* Thread-local text for the last non-zero return on this thread ("" if none). */
+const char *artemis_synth_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARTEMIS_SYNTH_H */
