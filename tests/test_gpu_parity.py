@@ -179,13 +179,22 @@ def test_nonfinite_and_huge_offsets_do_not_fault(dev, oracle):
     oy[0, 5, 0, 0] = np.nan
     ox[0, 6, 7, 7] = np.inf
     oy[0, 7, 8, 8] = -2147483648.0
+    # the five poisoned pixels hold meaningless (huge, cancelling or non-finite) values whose
+    # rounding is association-dependent; every other pixel must be unaffected and in tolerance
+    poisoned = np.zeros((20, 70), bool)
+    for y, x in ((1, 1), (2, 2), (0, 0), (7, 7), (8, 8)):
+        poisoned[y, x] = True
+    ref = oracle.forward(inp, w, oy, ox, 1)
+    rgi, rgw, rga, rgb = oracle.backward(gout, inp, w, oy, ox, 1)
     for radius in (-1, 0):
-        out, (gi, gw, ga, gb) = run_hip(dev, inp, w, oy, ox, gout, 1, radius)
-        ref = oracle.forward(inp, w, oy, ox, 1)
-        ok = np.isfinite(ref)
-        assert ok.mean() > 0.99
-        np.testing.assert_allclose(out[ok], ref[ok], rtol=FWD_RTOL, atol=FWD_RTOL)
-        assert np.array_equal(np.isfinite(out), ok)
+        out, (gi, gw, ga, gb) = run_hip(dev, inp, w, oy, ox, gout, 1, radius,
+                                        need=(False, True, True, True))
+        close(out[..., ~poisoned], ref[..., ~poisoned], FWD_RTOL)
+        close(gw[..., ~poisoned], rgw[..., ~poisoned], BWD_RTOL)
+        close(ga[..., ~poisoned], rga[..., ~poisoned], BWD_RTOL)
+        close(gb[..., ~poisoned], rgb[..., ~poisoned], BWD_RTOL)
+        # NaN / inf offsets poison exactly their own pixel, as in the oracle
+        assert np.array_equal(np.isfinite(out), np.isfinite(ref))
 
 
 def test_offset_radius_helper(dev):
