@@ -336,6 +336,29 @@ __device__ __forceinline__ void fill_tile(f32x4 *tile, const float *__restrict__
     }
 }
 
+// The 75 weight/offset planes and the gradient planes are touched exactly once per launch:
+// non-temporal accesses keep them from displacing the (re-read) frame in L2 and, measured on
+// MI355X, lift a mixed read/write stream from ~4.9 to ~6.3 TB/s (tools/exp/exp_bw.hip).
+#ifndef SYNTH_NT
+#define SYNTH_NT 1
+#endif
+__device__ __forceinline__ float ld_stream(const float *p)
+{
+#if SYNTH_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void st_stream(float *p, float v)
+{
+#if SYNTH_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 // One tap row (5 taps) of the three streamed planes for one pixel, held in registers.
 struct TapRow {
     float w[5], a[5], b[5];
@@ -352,9 +375,9 @@ __device__ __forceinline__ void load_tap_row(TapRow &t, const float *__restrict_
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
         const size_t o = (size_t)(r * 5 + s) * plane;
-        t.w[s] = (wrow + o)[x];
-        t.a[s] = (arow + o)[x];
-        t.b[s] = (brow + o)[x];
+        t.w[s] = ld_stream(wrow + o + x);
+        t.a[s] = ld_stream(arow + o + x);
+        t.b[s] = ld_stream(brow + o + x);
     }
 }
 
@@ -381,6 +404,34 @@ __device__ __forceinline__ Corners tile_corners(const lds_f32x4 *tile, int ly, i
     q.tl = p[LW];
     q.tr = p[LW + 1];
     return q;
+}
+
+// Same gather, with the out-of-tile test deferred: the caller keeps the running unsigned maxima
+// of ly and lx (a negative index is a huge unsigned) and tests them once per pixel.  Two v_max
+// per tap, and -- unlike a bool that is OR-ed up -- nothing the optimiser can postpone while
+// keeping every ly/lx of the pixel alive.
+template <int R, int TH>
+__device__ __forceinline__ Corners tile_corners_max(const lds_f32x4 *tile, int ly, int lx,
+                                                    unsigned &mly, unsigned &mlx)
+{
+    constexpr int LW = TileShape<R, TH>::LW, LH = TileShape<R, TH>::LH;
+    mly = max(mly, (unsigned)ly);
+    mlx = max(mlx, (unsigned)lx);
+    const unsigned idx = min(__umul24((unsigned)ly, (unsigned)LW) + (unsigned)lx,
+                             (unsigned)((LH - 1) * LW - 2));
+    const lds_f32x4 *p = tile + idx;
+    Corners q;
+    q.bl = p[0];
+    q.br = p[1];
+    q.tl = p[LW];
+    q.tr = p[LW + 1];
+    return q;
+}
+
+template <int R, int TH>
+__device__ __forceinline__ bool tile_missed(unsigned mly, unsigned mlx)
+{
+    return mly >= (unsigned)(TileShape<R, TH>::LH - 1) || mlx >= (unsigned)(TileShape<R, TH>::LW - 1);
 }
 
 template <int R, int TH>
@@ -452,9 +503,9 @@ __global__ __launch_bounds__(256, 4) void synth_fwd_tiled(const float *__restric
         // Stored unconditionally (a conditional store lets the optimiser sink the whole
         // accumulation past the loop); a lane with an out-of-tile tap then overwrites it.
         float *orow = out + (size_t)n * 3 * plane + (size_t)y * g.W;
-        orow[(unsigned)x] = acc0;
-        (orow + plane)[(unsigned)x] = acc1;
-        (orow + 2 * plane)[(unsigned)x] = acc2;
+        st_stream(orow + (unsigned)x, acc0);
+        st_stream(orow + plane + (unsigned)x, acc1);
+        st_stream(orow + 2 * plane + (unsigned)x, acc2);
         if (bad) fwd_pixel_direct<3>(ip, wrow + x, arow + x, brow + x, orow + x, g, y, x);
         if (!more) break;
         rowoff += (size_t)4 * g.W;
@@ -499,8 +550,8 @@ __global__ __launch_bounds__(256, 4) void synth_bwd_tiled(const float *__restric
         const bool more = py + 4 < TH && y + 4 < g.H;  // wave-uniform
         const float *wrow = w + rowoff, *arow = oy + rowoff, *brow = ox + rowoff;
         const float *grow = gout + (size_t)n * 3 * plane + (size_t)y * g.W;
-        const float d0 = grow[(unsigned)x], d1 = (grow + plane)[(unsigned)x],
-                    d2 = (grow + 2 * plane)[(unsigned)x];
+        const float d0 = ld_stream(grow + (unsigned)x), d1 = ld_stream(grow + plane + (unsigned)x),
+                    d2 = ld_stream(grow + 2 * plane + (unsigned)x);
         bool bad = false;
 #pragma unroll
         for (int r = 0; r < 5; ++r) {
@@ -526,10 +577,12 @@ __global__ __launch_bounds__(256, 4) void synth_bwd_tiled(const float *__restric
                 const float ga = 1.f - fa, gb = 1.f - fb;
                 const size_t t = rowoff + (size_t)(r * 5 + s) * plane;  // uniform
                 if (ALL || gw)
-                    (gw + t)[(unsigned)x] =
-                        pbl * (ga * gb) + ptl * (fa * gb) + pbr * (ga * fb) + ptr_ * (fa * fb);
-                if (ALL || goy) (goy + t)[(unsigned)x] = wv * ((ptl - pbl) * gb + (ptr_ - pbr) * fb);
-                if (ALL || gox) (gox + t)[(unsigned)x] = wv * ((pbr - pbl) * ga + (ptr_ - ptl) * fa);
+                    st_stream(gw + t + (unsigned)x, pbl * (ga * gb) + ptl * (fa * gb) +
+                                                        pbr * (ga * fb) + ptr_ * (fa * fb));
+                if (ALL || goy)
+                    st_stream(goy + t + (unsigned)x, wv * ((ptl - pbl) * gb + (ptr_ - pbr) * fb));
+                if (ALL || gox)
+                    st_stream(gox + t + (unsigned)x, wv * ((pbr - pbl) * ga + (ptr_ - ptl) * fa));
             }
             __builtin_amdgcn_sched_barrier(0);
             cur = nxt;
@@ -540,6 +593,223 @@ __global__ __launch_bounds__(256, 4) void synth_bwd_tiled(const float *__restric
                              gox ? gox + rowoff + x : nullptr, g, y, x);
         if (!more) break;
         rowoff += (size_t)4 * g.W;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Tap-major variants.  Same tile, same per-tap arithmetic, different loop order: a wave owns
+// ROWS pixel rows (tile = 64 x 4*ROWS) and walks the 25 taps in the OUTER loop, visiting its
+// rows inside each tap.  All workgroups of a residency round start together and advance through
+// the taps at about the same pace, so chip-wide only a few of the 75 (forward) / 150 (backward)
+// planes are being streamed at any moment and each plane is swept almost linearly.  HBM3E
+// needs that: measured on MI355X (tools/exp), 150 concurrent plane streams run at ~5.1 TB/s,
+// a handful at ~6.4-6.6 TB/s, because a DRAM row that is opened for 256 B costs as much as
+// one that delivers 1 KB.
+// ------------------------------------------------------------------------------------------
+
+#ifndef SYNTH_ROWGROUP
+#define SYNTH_ROWGROUP 4
+#endif
+constexpr int kRowGroup = SYNTH_ROWGROUP;  // rows whose LDS gathers may be in flight together
+
+template <int ROWS>
+struct TapCol {
+    float w[ROWS], a[ROWS], b[ROWS];
+};
+
+// wbase/abase/bbase: wave-uniform pointers to (tap 0, row of j = 0, x = 0) of this sample;
+// rowstep[j] is folded by the caller into `roff[j]` (uniform element offsets of the rows).
+template <int ROWS>
+__device__ __forceinline__ void load_tap_col(TapCol<ROWS> &t, const float *__restrict__ wbase,
+                                             const float *__restrict__ abase,
+                                             const float *__restrict__ bbase, size_t plane, int tap,
+                                             const size_t (&roff)[ROWS], unsigned x)
+{
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+        const size_t o = (size_t)tap * plane + roff[j];
+        t.w[j] = ld_stream(wbase + o + x);
+        t.a[j] = ld_stream(abase + o + x);
+        t.b[j] = ld_stream(bbase + o + x);
+    }
+}
+
+template <int R, int ROWS, int OCC>
+__global__ __launch_bounds__(256, OCC) void synth_fwd_tapmajor(const float *__restrict__ in,
+                                                                const float *__restrict__ w,
+                                                                const float *__restrict__ oy,
+                                                                const float *__restrict__ ox,
+                                                                float *__restrict__ out, Geom g)
+{
+    constexpr int TH = 4 * ROWS;
+    constexpr int LW = TileShape<R, TH>::LW, LH = TileShape<R, TH>::LH;
+    __shared__ f32x4 tile[LH * LW];
+    const lds_f32x4 *ltile = (const lds_f32x4 *)tile;
+    const int tx0 = blockIdx.x * kTW, ty0 = blockIdx.y * TH, n = blockIdx.z;
+    const int wy = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int tid = wy * 64 + threadIdx.x;
+    const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
+    const float *ip = in + (size_t)n * 3 * iplane;
+    const int px = threadIdx.x, x = tx0 + px;
+    const bool active = x < g.W && ty0 + wy < g.H;
+    const float *wb = w + (size_t)n * 25 * plane, *ab = oy + (size_t)n * 25 * plane,
+                *bb = ox + (size_t)n * 25 * plane;
+
+    // A row past the bottom edge is replaced by the last image row: the wave then recomputes
+    // and re-stores exactly what that row's owner stores (same operands, same arithmetic), which
+    // keeps the unrolled body free of per-row branches.
+    int rowy[ROWS];
+    size_t roff[ROWS];
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+        rowy[j] = min(ty0 + wy + 4 * j, g.H - 1);
+        roff[j] = (size_t)rowy[j] * g.W;
+    }
+
+    TapCol<ROWS> cur;
+    if (active) load_tap_col<ROWS>(cur, wb, ab, bb, plane, 0, roff, (unsigned)x);
+
+    fill_tile<R, TH>(tile, ip, g, ty0 + g.oy0 - R, tx0 + g.ox0 - R, tid);
+    __syncthreads();
+    if (!active) return;
+
+    float acc[ROWS][3];
+    unsigned mly[ROWS], mlx[ROWS];
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+        acc[j][0] = acc[j][1] = acc[j][2] = 0.f;
+        mly[j] = mlx[j] = 0;
+    }
+#pragma unroll
+    for (int t = 0; t < 25; ++t) {
+        const int r = t / 5, s = t % 5;
+        TapCol<ROWS> nxt;
+        if (t < 24) load_tap_col<ROWS>(nxt, wb, ab, bb, plane, t + 1, roff, (unsigned)x);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {
+            const float wv = cur.w[j], a = cur.a[j], b = cur.b[j];
+            const int ia = (int)a, ib = (int)b;
+            const float fa = a - (float)ia, fb = b - (float)ib;
+            const Corners q = tile_corners_max<R, TH>(ltile, wadd(rowy[j] - ty0 + r + R, ia),
+                                                      wadd(px + s + R, ib), mly[j], mlx[j]);
+            const float ga = 1.f - fa, gb = 1.f - fb;
+            const float c00 = ga * gb, c10 = fa * gb, c01 = ga * fb, c11 = fa * fb;
+            acc[j][0] += wv * (q.bl.x * c00 + q.tl.x * c10 + q.br.x * c01 + q.tr.x * c11);
+            acc[j][1] += wv * (q.bl.y * c00 + q.tl.y * c10 + q.br.y * c01 + q.tr.y * c11);
+            acc[j][2] += wv * (q.bl.z * c00 + q.tl.z * c10 + q.br.z * c01 + q.tr.z * c11);
+            // pin the arithmetic in place (see synth_fwd_tiled) and bound the LDS results in
+            // flight to kRowGroup rows (16 VGPRs each)
+            asm volatile("" : "+v"(acc[j][0]), "+v"(acc[j][1]), "+v"(acc[j][2]), "+v"(mly[j]),
+                         "+v"(mlx[j]));
+            if (j % kRowGroup == kRowGroup - 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+    }
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+        const int y = rowy[j];
+        float *orow = out + (size_t)n * 3 * plane + roff[j];
+        st_stream(orow + (unsigned)x, acc[j][0]);
+        st_stream(orow + plane + (unsigned)x, acc[j][1]);
+        st_stream(orow + 2 * plane + (unsigned)x, acc[j][2]);
+        if (tile_missed<R, TH>(mly[j], mlx[j])) {
+            const size_t o = roff[j] + x;
+            fwd_pixel_direct<3>(ip, wb + o, ab + o, bb + o, orow + x, g, y, x);
+        }
+    }
+}
+
+template <int R, int ROWS, int OCC, bool ALL>
+__global__ __launch_bounds__(256, OCC) void synth_bwd_tapmajor(const float *__restrict__ in,
+                                                                const float *__restrict__ w,
+                                                                const float *__restrict__ oy,
+                                                                const float *__restrict__ ox,
+                                                                const float *__restrict__ gout,
+                                                                float *__restrict__ gw,
+                                                                float *__restrict__ goy,
+                                                                float *__restrict__ gox, Geom g)
+{
+    constexpr int TH = 4 * ROWS;
+    constexpr int LW = TileShape<R, TH>::LW, LH = TileShape<R, TH>::LH;
+    __shared__ f32x4 tile[LH * LW];
+    const lds_f32x4 *ltile = (const lds_f32x4 *)tile;
+    const int tx0 = blockIdx.x * kTW, ty0 = blockIdx.y * TH, n = blockIdx.z;
+    const int wy = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int tid = wy * 64 + threadIdx.x;
+    const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
+    const float *ip = in + (size_t)n * 3 * iplane;
+    const int px = threadIdx.x, x = tx0 + px;
+    const bool active = x < g.W && ty0 + wy < g.H;
+    const size_t nb = (size_t)n * 25 * plane;
+    const float *wb = w + nb, *ab = oy + nb, *bb = ox + nb;
+
+    int rowy[ROWS];  // rows past the bottom edge duplicate the last image row (see forward)
+    size_t roff[ROWS];
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+        rowy[j] = min(ty0 + wy + 4 * j, g.H - 1);
+        roff[j] = (size_t)rowy[j] * g.W;
+    }
+
+    TapCol<ROWS> cur;
+    if (active) load_tap_col<ROWS>(cur, wb, ab, bb, plane, 0, roff, (unsigned)x);
+
+    fill_tile<R, TH>(tile, ip, g, ty0 + g.oy0 - R, tx0 + g.ox0 - R, tid);
+    __syncthreads();
+    if (!active) return;
+
+    float d[ROWS][3];
+    unsigned mly[ROWS], mlx[ROWS];
+    const float *gb_ = gout + (size_t)n * 3 * plane;
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+        d[j][0] = ld_stream(gb_ + roff[j] + (unsigned)x);
+        d[j][1] = ld_stream(gb_ + plane + roff[j] + (unsigned)x);
+        d[j][2] = ld_stream(gb_ + 2 * plane + roff[j] + (unsigned)x);
+        mly[j] = mlx[j] = 0;
+    }
+#pragma unroll
+    for (int t = 0; t < 25; ++t) {
+        const int r = t / 5, s = t % 5;
+        TapCol<ROWS> nxt;
+        if (t < 24) load_tap_col<ROWS>(nxt, wb, ab, bb, plane, t + 1, roff, (unsigned)x);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {
+            const float wv = cur.w[j], a = cur.a[j], b = cur.b[j];
+            const int ia = (int)a, ib = (int)b;
+            const float fa = a - (float)ia, fb = b - (float)ib;
+            const Corners q = tile_corners_max<R, TH>(ltile, wadd(rowy[j] - ty0 + r + R, ia),
+                                                      wadd(px + s + R, ib), mly[j], mlx[j]);
+            const float pbl = d[j][0] * q.bl.x + d[j][1] * q.bl.y + d[j][2] * q.bl.z;
+            const float ptl = d[j][0] * q.tl.x + d[j][1] * q.tl.y + d[j][2] * q.tl.z;
+            const float pbr = d[j][0] * q.br.x + d[j][1] * q.br.y + d[j][2] * q.br.z;
+            const float ptr_ = d[j][0] * q.tr.x + d[j][1] * q.tr.y + d[j][2] * q.tr.z;
+            const float ga = 1.f - fa, gb = 1.f - fb;
+            const size_t o = nb + (size_t)t * plane + roff[j];
+            if (ALL || gw)
+                st_stream(gw + o + (unsigned)x, pbl * (ga * gb) + ptl * (fa * gb) +
+                                                    pbr * (ga * fb) + ptr_ * (fa * fb));
+            if (ALL || goy)
+                st_stream(goy + o + (unsigned)x, wv * ((ptl - pbl) * gb + (ptr_ - pbr) * fb));
+            if (ALL || gox)
+                st_stream(gox + o + (unsigned)x, wv * ((pbr - pbl) * ga + (ptr_ - ptl) * fa));
+            asm volatile("" : "+v"(mly[j]), "+v"(mlx[j]));
+            if (j % kRowGroup == kRowGroup - 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+    }
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+        const int y = rowy[j];
+        if (tile_missed<R, TH>(mly[j], mlx[j])) {
+            const size_t o = roff[j] + x;
+            bwd_pixel_direct(ip, wb + o, ab + o, bb + o, gb_ + o, gw ? gw + nb + o : nullptr,
+                             goy ? goy + nb + o : nullptr, gox ? gox + nb + o : nullptr, g, y, x);
+        }
     }
 }
 
@@ -604,6 +874,22 @@ int make_geom(Geom &g, int N, int C, int H, int W, int k, int d)
     return 0;
 }
 
+// Kernel structure, chosen at build time (tools/ab.py compares builds in one process):
+//   SYNTH_TAPMAJOR 0: row-major tap loop (synth_*_tiled, tile 64 x 16)
+//                  1: tap-major (synth_*_tapmajor, tile 64 x 4*SYNTH_ROWS)
+#ifndef SYNTH_TAPMAJOR
+#define SYNTH_TAPMAJOR 1
+#endif
+#ifndef SYNTH_ROWS
+#define SYNTH_ROWS 8
+#endif
+#ifndef SYNTH_OCC
+#define SYNTH_OCC 2
+#endif
+#ifndef SYNTH_BWD_TAPMAJOR
+#define SYNTH_BWD_TAPMAJOR SYNTH_TAPMAJOR
+#endif
+
 // tile radii built for the LDS-staged kernels (TH = 16)
 constexpr int kTileTH = 16;
 constexpr int kDefaultRadius = 4;
@@ -629,8 +915,13 @@ template <int R>
 void launch_fwd_tiled(const float *in, const float *w, const float *oy, const float *ox, float *out,
                       const Geom &g, hipStream_t st)
 {
+#if SYNTH_TAPMAJOR
+    hipLaunchKernelGGL((synth_fwd_tapmajor<R, SYNTH_ROWS, SYNTH_OCC>), pixel_grid(g, 4 * SYNTH_ROWS),
+                       dim3(64, 4), 0, st, in, w, oy, ox, out, g);
+#else
     hipLaunchKernelGGL((synth_fwd_tiled<R, kTileTH>), pixel_grid(g, kTileTH), dim3(64, 4), 0, st, in,
                        w, oy, ox, out, g);
+#endif
 }
 
 template <int R>
@@ -638,12 +929,23 @@ void launch_bwd_tiled(const float *in, const float *w, const float *oy, const fl
                       const float *gout, float *gw, float *goy, float *gox, const Geom &g,
                       hipStream_t st)
 {
+#if SYNTH_BWD_TAPMAJOR
+    if (gw && goy && gox)
+        hipLaunchKernelGGL((synth_bwd_tapmajor<R, SYNTH_ROWS, SYNTH_OCC, true>),
+                           pixel_grid(g, 4 * SYNTH_ROWS), dim3(64, 4), 0, st, in, w, oy, ox, gout, gw,
+                           goy, gox, g);
+    else
+        hipLaunchKernelGGL((synth_bwd_tapmajor<R, SYNTH_ROWS, SYNTH_OCC, false>),
+                           pixel_grid(g, 4 * SYNTH_ROWS), dim3(64, 4), 0, st, in, w, oy, ox, gout, gw,
+                           goy, gox, g);
+#else
     if (gw && goy && gox)
         hipLaunchKernelGGL((synth_bwd_tiled<R, kTileTH, true>), pixel_grid(g, kTileTH), dim3(64, 4), 0,
                            st, in, w, oy, ox, gout, gw, goy, gox, g);
     else
         hipLaunchKernelGGL((synth_bwd_tiled<R, kTileTH, false>), pixel_grid(g, kTileTH), dim3(64, 4), 0,
                            st, in, w, oy, ox, gout, gw, goy, gox, g);
+#endif
 }
 
 int count_bits_for(const Geom &g)

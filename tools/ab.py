@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""A/B builds of libartemis_synth in ONE process, interleaved rounds, cold operands (4 rotating
+1080p frame sets as in bench.py).  usage: python tools/ab.py libA.so libB.so ... [--sigma S]
+[--radius R] [--shape N,H,W]"""
+import argparse
+import ctypes
+import os
+import statistics
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from artemis_amd import _lib  # noqa: E402
+
+
+def bind(path):
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in _lib.SIGNATURES.items():
+        if hasattr(lib, name):
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+    return lib
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("libs", nargs="+")
+    ap.add_argument("--sigma", type=float, default=1.0)
+    ap.add_argument("--radius", type=int, default=-1)
+    ap.add_argument("--rounds", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=1)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    libs = [(os.path.basename(p), bind(p if os.path.isabs(p) else os.path.join(ROOT, p))) for p in a.libs]
+    frames = bench.make_frames(a.batch, a.sigma, dev, 103)
+    st = torch.cuda.current_stream().cuda_stream
+    H, W, B = bench.H, bench.W, a.batch
+
+    def fwd(lib, f):
+        assert lib.artemis_synth_forward(f["inp"].data_ptr(), f["w"].data_ptr(), f["oy"].data_ptr(),
+                                         f["ox"].data_ptr(), f["out"].data_ptr(), B, 3, H, W, 5, 1,
+                                         a.radius, st) == 0
+
+    def bwd(lib, f):
+        assert lib.artemis_synth_backward(f["inp"].data_ptr(), f["w"].data_ptr(), f["oy"].data_ptr(),
+                                          f["ox"].data_ptr(), f["gout"].data_ptr(), None,
+                                          f["gw"].data_ptr(), f["ga"].data_ptr(), f["gb"].data_ptr(),
+                                          B, 3, H, W, 5, 1, 0, a.radius, None, 0, st) == 0
+
+    T = {(n, k): [] for n, _ in libs for k in ("fwd", "bwd")}
+    for rnd in range(a.rounds + 1):
+        for name, lib in libs:
+            for kind, fn in (("fwd", fwd), ("bwd", bwd)):
+                evs = []
+                for f in frames:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    fn(lib, f)
+                    e1.record()
+                    evs.append((e0, e1))
+                torch.cuda.synchronize()
+                if rnd:
+                    T[(name, kind)].append(sum(x.elapsed_time(y) for x, y in evs) / len(evs))
+    px = B * H * W
+    for (name, kind), ts in T.items():
+        med = statistics.median(ts)
+        nb = (324.0 if kind == "fwd" else 624.0) * px
+        print(f"{name:32s} {kind}: median {med*1e3:8.1f} us  min {min(ts)*1e3:8.1f} us  {nb/med/1e6:7.0f} GB/s")
+    for name, _ in libs:
+        tot = statistics.median(T[(name, "fwd")]) + statistics.median(T[(name, "bwd")])
+        print(f"{name:32s} step(4 frames) {4*tot:7.3f} ms -> {px/(4*tot)/1e3:8.1f} Mpix/s "
+              f"({px*3792/(4*tot*1e-3)/8e12*100:5.1f}% of 8 TB/s)")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,467 @@
+// Experiment: pure streaming of the 75 planes in the product's access pattern, to find how
+// achieved HBM bandwidth depends on bytes in flight (prefetch depth x occupancy) and load width.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// DEPTH = tap rows (15 loads each) in flight ahead of the one being consumed; LDSB = dummy LDS
+// bytes per block (caps blocks/CU); each wave streams rows wy, wy+4, ... of a 64 x TH tile.
+template <int DEPTH, int LDSB, int TH>
+__global__ __launch_bounds__(256) void stream1(const float *__restrict__ w, const float *__restrict__ oy,
+                                                const float *__restrict__ ox, float *__restrict__ out,
+                                                int H, int W)
+{
+    __shared__ float dummy[LDSB / 4];
+    if (LDSB > 4 && threadIdx.x == 999) dummy[threadIdx.y] = 0;  // keep the allocation
+    const int tx0 = blockIdx.x * 64, ty0 = blockIdx.y * TH;
+    const int wy = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const unsigned x = tx0 + threadIdx.x;
+    if ((int)x >= W) return;
+    const size_t plane = (size_t)H * W;
+    constexpr int ROWS = TH / 4;       // pixel rows per wave
+    constexpr int STEPS = ROWS * 5;    // tap rows per wave
+    float buf[DEPTH + 1][15];
+    float acc0 = 0, acc1 = 0, acc2 = 0;
+    auto issue = [&](int step, float *dst) {
+        const int prow = step / 5, r = step % 5;
+        const int y = ty0 + wy + 4 * prow;
+        const size_t ro = (size_t)min(y, H - 1) * W;
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            const size_t o = ro + (size_t)(r * 5 + s) * plane;
+            dst[3 * s] = (w + o)[x];
+            dst[3 * s + 1] = (oy + o)[x];
+            dst[3 * s + 2] = (ox + o)[x];
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i) issue(i, buf[i]);
+#pragma unroll
+    for (int step = 0; step < STEPS; ++step) {
+        if (step + DEPTH < STEPS) issue(step + DEPTH, buf[(step + DEPTH) % (DEPTH + 1)]);
+        __builtin_amdgcn_sched_barrier(0);
+        float *c = buf[step % (DEPTH + 1)];
+#pragma unroll
+        for (int s = 0; s < 5; ++s) { acc0 += c[3 * s]; acc1 += c[3 * s + 1]; acc2 += c[3 * s + 2]; }
+        asm volatile("" : "+v"(acc0), "+v"(acc1), "+v"(acc2));
+        __builtin_amdgcn_sched_barrier(0);
+        if (step % 5 == 4) {
+            const int y = ty0 + wy + 4 * (step / 5);
+            if (y < H) {
+                float *orow = out + (size_t)y * W;
+                orow[x] = acc0; (orow + plane)[x] = acc1; (orow + 2 * plane)[x] = acc2;
+            }
+            acc0 = acc1 = acc2 = 0;
+        }
+    }
+}
+
+// dwordx4 variant: a lane owns 4 consecutive x; a wave covers 256 x of one row; block (64,4)
+template <int DEPTH, int LDSB, int TH>
+__global__ __launch_bounds__(256) void stream4(const float *__restrict__ w, const float *__restrict__ oy,
+                                                const float *__restrict__ ox, float *__restrict__ out,
+                                                int H, int W)
+{
+    __shared__ float dummy[LDSB / 4];
+    if (LDSB > 4 && threadIdx.x == 999) dummy[threadIdx.y] = 0;
+    const int tx0 = blockIdx.x * 256, ty0 = blockIdx.y * TH;
+    const int wy = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const unsigned x = tx0 + 4 * threadIdx.x;
+    if ((int)x >= W) return;
+    const size_t plane = (size_t)H * W;
+    constexpr int ROWS = TH / 4;
+    constexpr int STEPS = ROWS * 5;
+    f32x4 buf[DEPTH + 1][15];
+    f32x4 acc0 = 0, acc1 = 0, acc2 = 0;
+    auto issue = [&](int step, f32x4 *dst) {
+        const int prow = step / 5, r = step % 5;
+        const int y = ty0 + wy + 4 * prow;
+        const size_t ro = (size_t)min(y, H - 1) * W;
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            const size_t o = ro + (size_t)(r * 5 + s) * plane;
+            dst[3 * s] = *(const f32x4 *)(w + o + x);
+            dst[3 * s + 1] = *(const f32x4 *)(oy + o + x);
+            dst[3 * s + 2] = *(const f32x4 *)(ox + o + x);
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i) issue(i, buf[i]);
+#pragma unroll
+    for (int step = 0; step < STEPS; ++step) {
+        if (step + DEPTH < STEPS) issue(step + DEPTH, buf[(step + DEPTH) % (DEPTH + 1)]);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 *c = buf[step % (DEPTH + 1)];
+#pragma unroll
+        for (int s = 0; s < 5; ++s) { acc0 += c[3 * s]; acc1 += c[3 * s + 1]; acc2 += c[3 * s + 2]; }
+        asm volatile("" : "+v"(acc0), "+v"(acc1), "+v"(acc2));
+        __builtin_amdgcn_sched_barrier(0);
+        if (step % 5 == 4) {
+            const int y = ty0 + wy + 4 * (step / 5);
+            if (y < H) {
+                float *orow = out + (size_t)y * W + x;
+                *(f32x4 *)orow = acc0; *(f32x4 *)(orow + plane) = acc1; *(f32x4 *)(orow + 2 * plane) = acc2;
+            }
+            acc0 = acc1 = acc2 = 0;
+        }
+    }
+}
+
+
+// persistent: grid of G blocks; block b walks tiles b, b+G, ... of 64 x 4 (one row per wave),
+// so that at any moment the resident blocks read a contiguous band of rows of each plane.
+template <int DEPTH, int LDSB>
+__global__ __launch_bounds__(256) void stream_persist(const float *__restrict__ w, const float *__restrict__ oy,
+                                                       const float *__restrict__ ox, float *__restrict__ out,
+                                                       int H, int W)
+{
+    __shared__ float dummy[LDSB / 4];
+    if (LDSB > 4 && threadIdx.x == 999) dummy[threadIdx.y] = 0;
+    const int wy = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int tiles_x = (W + 63) / 64, tiles_y = (H + 3) / 4;
+    const int ntiles = tiles_x * tiles_y;
+    const size_t plane = (size_t)H * W;
+    float buf[2][15];
+    auto issue = [&](int tile, int r, float *dst) {
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const int y = min(ty * 4 + wy, H - 1);
+        const unsigned x = min(tx * 64 + (int)threadIdx.x, W - 1);
+        const size_t ro = (size_t)y * W;
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            const size_t o = ro + (size_t)(r * 5 + s) * plane;
+            dst[3 * s] = (w + o)[x];
+            dst[3 * s + 1] = (oy + o)[x];
+            dst[3 * s + 2] = (ox + o)[x];
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    issue(tile, 0, buf[0]);
+#pragma unroll 1
+    for (; tile < ntiles; tile += gridDim.x) {
+        float acc0 = 0, acc1 = 0, acc2 = 0;
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            if (r < 4) issue(tile, r + 1, buf[(r + 1) & 1]);
+            else if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x, 0, buf[(r + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            float *c = buf[r & 1];
+#pragma unroll
+            for (int s = 0; s < 5; ++s) { acc0 += c[3 * s]; acc1 += c[3 * s + 1]; acc2 += c[3 * s + 2]; }
+            asm volatile("" : "+v"(acc0), "+v"(acc1), "+v"(acc2));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // r=4 wrote buf[1]; next tile's r=0 expects buf[0]
+#pragma unroll
+        for (int i = 0; i < 15; ++i) buf[0][i] = buf[1][i];
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const int y = ty * 4 + wy, x = tx * 64 + threadIdx.x;
+        if (y < H && x < W) {
+            float *orow = out + (size_t)y * W;
+            orow[x] = acc0; (orow + plane)[x] = acc1; (orow + 2 * plane)[x] = acc2;
+        }
+    }
+}
+
+// backward-like stream: read the 75 planes (+3 gout planes), write 75 planes, trivial math.
+template <int LDSB, int TH, int WAVES, bool NT>
+__global__ __launch_bounds__(WAVES * 64) void streamb(const float *__restrict__ w, const float *__restrict__ oy,
+                                                const float *__restrict__ ox, float *__restrict__ gw,
+                                                float *__restrict__ ga, float *__restrict__ gb,
+                                                int H, int W)
+{
+    __shared__ float dummy[LDSB / 4];
+    if (LDSB > 4 && threadIdx.x == 999) dummy[threadIdx.y] = 0;
+    const int tx0 = blockIdx.x * 64, ty0 = blockIdx.y * TH;
+    const int wy = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const unsigned x = tx0 + threadIdx.x;
+    if ((int)x >= W) return;
+    const size_t plane = (size_t)H * W;
+    constexpr int ROWS = TH / WAVES;
+    constexpr int STEPS = ROWS * 5;
+    float buf[2][15];
+    auto issue = [&](int step, float *dst) {
+        const int prow = step / 5, r = step % 5;
+        const int y = ty0 + wy + WAVES * prow;
+        const size_t ro = (size_t)min(y, H - 1) * W;
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            const size_t o = ro + (size_t)(r * 5 + s) * plane;
+            dst[3 * s] = NT ? __builtin_nontemporal_load(w + o + x) : (w + o)[x];
+            dst[3 * s + 1] = NT ? __builtin_nontemporal_load(oy + o + x) : (oy + o)[x];
+            dst[3 * s + 2] = NT ? __builtin_nontemporal_load(ox + o + x) : (ox + o)[x];
+        }
+    };
+    issue(0, buf[0]);
+#pragma unroll
+    for (int step = 0; step < STEPS; ++step) {
+        if (step + 1 < STEPS) issue(step + 1, buf[(step + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        float *c = buf[step & 1];
+        const int prow = step / 5, r = step % 5;
+        const int y = ty0 + wy + WAVES * prow;
+        if (y < H) {
+            const size_t ro = (size_t)y * W;
+#pragma unroll
+            for (int s = 0; s < 5; ++s) {
+                const size_t o = ro + (size_t)(r * 5 + s) * plane;
+                const float v0 = c[3 * s] * 1.5f, v1 = c[3 * s + 1] + c[3 * s], v2 = c[3 * s + 2] - c[3 * s];
+                if (NT) {
+                    __builtin_nontemporal_store(v0, gw + o + x);
+                    __builtin_nontemporal_store(v1, ga + o + x);
+                    __builtin_nontemporal_store(v2, gb + o + x);
+                } else {
+                    (gw + o)[x] = v0; (ga + o)[x] = v1; (gb + o)[x] = v2;
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+template <int LDSB, int TH, int WAVES, bool NT>
+static void lb(const float *w, const float *oy, const float *ox, float *gw, float *ga, float *gb, int H, int W, hipStream_t st)
+{
+    hipLaunchKernelGGL((streamb<LDSB, TH, WAVES, NT>), dim3((W + 63) / 64, (H + TH - 1) / TH), dim3(64, WAVES), 0, st, w, oy, ox, gw, ga, gb, H, W);
+}
+
+// backward-like stream with the tap rows split across grid.z: a block streams only tap row
+// blockIdx.z (15 planes in, 15 planes out) for its 64 x TH pixels -> 30 concurrently active
+// plane streams chip-wide instead of 150 (blocks dispatch z-major last).
+template <int LDSB, int TH, int WAVES, bool NT, int TAPS, int ORDER = 0>
+__global__ __launch_bounds__(WAVES * 64) void streamb_split(const float *__restrict__ w, const float *__restrict__ oy,
+                                                const float *__restrict__ ox, float *__restrict__ gw,
+                                                float *__restrict__ ga, float *__restrict__ gb,
+                                                int H, int W)
+{
+    __shared__ float dummy[LDSB / 4];
+    if (LDSB > 4 && threadIdx.x == 999) dummy[threadIdx.y] = 0;
+    const int tx0 = (ORDER ? blockIdx.y : blockIdx.x) * 64, ty0 = (ORDER ? blockIdx.z : blockIdx.y) * TH;
+    const int t0 = (ORDER ? blockIdx.x : blockIdx.z) * TAPS;
+    const int wy = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const unsigned x = tx0 + threadIdx.x;
+    if ((int)x >= W) return;
+    const size_t plane = (size_t)H * W;
+    constexpr int ROWS = TH / WAVES;
+    float buf[2][3 * TAPS];
+    auto issue = [&](int prow, float *dst) {
+        const int y = ty0 + wy + WAVES * prow;
+        const size_t ro = (size_t)min(y, H - 1) * W;
+#pragma unroll
+        for (int s = 0; s < TAPS; ++s) {
+            const size_t o = ro + (size_t)(t0 + s) * plane;
+            dst[3 * s] = NT ? __builtin_nontemporal_load(w + o + x) : (w + o)[x];
+            dst[3 * s + 1] = NT ? __builtin_nontemporal_load(oy + o + x) : (oy + o)[x];
+            dst[3 * s + 2] = NT ? __builtin_nontemporal_load(ox + o + x) : (ox + o)[x];
+        }
+    };
+    issue(0, buf[0]);
+#pragma unroll
+    for (int prow = 0; prow < ROWS; ++prow) {
+        if (prow + 1 < ROWS) issue(prow + 1, buf[(prow + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        float *c = buf[prow & 1];
+        const int y = ty0 + wy + WAVES * prow;
+        if (y < H) {
+            const size_t ro = (size_t)y * W;
+#pragma unroll
+            for (int s = 0; s < TAPS; ++s) {
+                const size_t o = ro + (size_t)(t0 + s) * plane;
+                const float v0 = c[3 * s] * 1.5f, v1 = c[3 * s + 1] + c[3 * s], v2 = c[3 * s + 2] - c[3 * s];
+                if (NT) {
+                    __builtin_nontemporal_store(v0, gw + o + x);
+                    __builtin_nontemporal_store(v1, ga + o + x);
+                    __builtin_nontemporal_store(v2, gb + o + x);
+                } else {
+                    (gw + o)[x] = v0; (ga + o)[x] = v1; (gb + o)[x] = v2;
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+template <int LDSB, int TH, int WAVES, bool NT, int TAPS>
+static void lbs1(const float *w, const float *oy, const float *ox, float *gw, float *ga, float *gb, int H, int W, hipStream_t st)
+{
+    hipLaunchKernelGGL((streamb_split<LDSB, TH, WAVES, NT, TAPS, 1>), dim3(25 / TAPS, (W + 63) / 64, (H + TH - 1) / TH), dim3(64, WAVES), 0, st, w, oy, ox, gw, ga, gb, H, W);
+}
+template <int LDSB, int TH, int WAVES, bool NT, int TAPS>
+static void lbs(const float *w, const float *oy, const float *ox, float *gw, float *ga, float *gb, int H, int W, hipStream_t st)
+{
+    hipLaunchKernelGGL((streamb_split<LDSB, TH, WAVES, NT, TAPS>), dim3((W + 63) / 64, (H + TH - 1) / TH, 25 / TAPS), dim3(64, WAVES), 0, st, w, oy, ox, gw, ga, gb, H, W);
+}
+
+// tap-major order inside a block: for tap t: for the wave's ROWS rows: stream 3 planes (+ write 3
+// planes when BWD).  All blocks of a residency round start together, so chip-wide only a few
+// planes are active at any moment.
+template <int LDSB, int TH, bool BWD, int NT>
+__global__ __launch_bounds__(256) void stream_tapmajor(const float *__restrict__ w, const float *__restrict__ oy,
+                                                const float *__restrict__ ox, float *__restrict__ gw,
+                                                float *__restrict__ ga, float *__restrict__ gb,
+                                                int H, int W)
+{
+    __shared__ float dummy[LDSB / 4];
+    if (LDSB > 4 && threadIdx.x == 999) dummy[threadIdx.y] = 0;
+    const int tx0 = blockIdx.x * 64, ty0 = blockIdx.y * TH;
+    const int wy = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const unsigned x = tx0 + threadIdx.x;
+    if ((int)x >= W) return;
+    const size_t plane = (size_t)H * W;
+    constexpr int ROWS = TH / 4;
+    float buf[2][3 * ROWS];
+    float acc[3 * ROWS];
+#pragma unroll
+    for (int i = 0; i < 3 * ROWS; ++i) acc[i] = 0;
+    auto issue = [&](int t, float *dst) {
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {
+            const int y = min(ty0 + wy + 4 * j, H - 1);
+            const size_t o = (size_t)y * W + (size_t)t * plane;
+            dst[3 * j] = (NT & 1) ? __builtin_nontemporal_load(w + o + x) : (w + o)[x];
+            dst[3 * j + 1] = (NT & 1) ? __builtin_nontemporal_load(oy + o + x) : (oy + o)[x];
+            dst[3 * j + 2] = (NT & 1) ? __builtin_nontemporal_load(ox + o + x) : (ox + o)[x];
+        }
+    };
+    issue(0, buf[0]);
+#pragma unroll
+    for (int t = 0; t < 25; ++t) {
+        if (t + 1 < 25) issue(t + 1, buf[(t + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        float *c = buf[t & 1];
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {
+            const int y = ty0 + wy + 4 * j;
+            if (BWD) {
+                if (y < H) {
+                    const size_t o = (size_t)y * W + (size_t)t * plane;
+                    const float v0 = c[3 * j] * 1.5f, v1 = c[3 * j + 1] + c[3 * j], v2 = c[3 * j + 2] - c[3 * j];
+                    if (NT & 2) {
+                        __builtin_nontemporal_store(v0, gw + o + x);
+                        __builtin_nontemporal_store(v1, ga + o + x);
+                        __builtin_nontemporal_store(v2, gb + o + x);
+                    } else { (gw + o)[x] = v0; (ga + o)[x] = v1; (gb + o)[x] = v2; }
+                }
+            } else {
+                acc[3 * j] += c[3 * j]; acc[3 * j + 1] += c[3 * j + 1]; acc[3 * j + 2] += c[3 * j + 2];
+            }
+        }
+        if (!BWD) {
+#pragma unroll
+            for (int i = 0; i < 3 * ROWS; ++i) asm volatile("" : "+v"(acc[i]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!BWD) {
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {
+            const int y = ty0 + wy + 4 * j;
+            if (y < H) {
+                float *orow = gw + (size_t)y * W;
+                orow[x] = acc[3 * j]; (orow + plane)[x] = acc[3 * j + 1]; (orow + 2 * plane)[x] = acc[3 * j + 2];
+            }
+        }
+    }
+}
+template <int LDSB, int TH, bool BWD, int NT>
+static void ltm(const float *w, const float *oy, const float *ox, float *gw, float *ga, float *gb, int H, int W, hipStream_t st)
+{
+    hipLaunchKernelGGL((stream_tapmajor<LDSB, TH, BWD, NT>), dim3((W + 63) / 64, (H + TH - 1) / TH), dim3(64, 4), 0, st, w, oy, ox, gw, ga, gb, H, W);
+}
+
+template <int DEPTH, int LDSB, int TH>
+static void l1(const float *w, const float *oy, const float *ox, float *out, int H, int W, hipStream_t st)
+{
+    hipLaunchKernelGGL((stream1<DEPTH, LDSB, TH>), dim3((W + 63) / 64, (H + TH - 1) / TH), dim3(64, 4), 0, st, w, oy, ox, out, H, W);
+}
+template <int DEPTH, int LDSB, int TH>
+static void l4(const float *w, const float *oy, const float *ox, float *out, int H, int W, hipStream_t st)
+{
+    hipLaunchKernelGGL((stream4<DEPTH, LDSB, TH>), dim3((W + 255) / 256, (H + TH - 1) / TH), dim3(64, 4), 0, st, w, oy, ox, out, H, W);
+}
+
+extern "C" int exp_runb(int variant, const float *w, const float *oy, const float *ox, float *gw, float *ga, float *gb, int H, int W, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    constexpr int L4 = 40960, L8 = 4;
+    switch (variant) {
+    case 0: lb<L4, 16, 4, false>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 1: lb<L4, 16, 4, true>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 2: lb<L8, 16, 4, true>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 3: lb<L4, 8, 4, true>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 4: lb<L8, 8, 4, true>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 5: lb<L4, 4, 4, true>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 6: lb<L8, 4, 4, true>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 7: lb<L8, 4, 4, false>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 8: lb<L8, 2, 2, true>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 9: lb<L8, 1, 1, true>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 10: lb<L4, 32, 4, true>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 11: lbs<L4, 16, 4, false, 5>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 12: lbs<L4, 16, 4, true, 5>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 13: lbs<L8, 16, 4, true, 5>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 14: lbs<L4, 32, 4, true, 5>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 15: lbs<L4, 64, 4, true, 5>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 16: lbs<L4, 16, 4, true, 1>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 17: lbs<L4, 64, 4, true, 1>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 18: lbs<L8, 64, 4, false, 1>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 19: lbs1<L4, 16, 4, true, 1>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 20: lbs1<L4, 16, 4, true, 5>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 21: lbs<L4, 16, 4, false, 1>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 22: lbs<L8, 16, 4, true, 1>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 23: lbs<L4, 8, 4, true, 1>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 24: lbs<L4, 32, 4, true, 1>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 30: ltm<L4, 16, true, 3>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 31: ltm<L4, 16, true, 0>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 32: ltm<L4, 32, true, 3>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 33: ltm<L4, 8, true, 3>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 34: ltm<L8, 16, true, 3>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 35: ltm<L4, 16, false, 3>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 36: ltm<L4, 16, false, 0>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 37: ltm<L4, 32, false, 3>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 38: ltm<L4, 8, false, 3>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 39: ltm<L8, 16, false, 3>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 40: ltm<L4, 32, true, 0>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 41: ltm<L4, 32, true, 1>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 42: ltm<L4, 32, true, 2>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 43: ltm<81920, 32, true, 3>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 44: ltm<81920, 32, false, 3>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 45: ltm<L4, 32, false, 0>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 46: ltm<54000, 32, false, 3>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 47: ltm<54000, 32, true, 3>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    default: return -1;
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int exp_run(int variant, const float *in, const float *w, const float *oy, const float *ox,
+                       float *out, int N, int H, int W, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    constexpr int L4 = 40960, L5 = 32768, L6 = 27000, L8 = 4;  // blocks/CU 4,5,6,8
+    switch (variant) {
+    case 0: l1<1, L4, 16>(w, oy, ox, out, H, W, st); break;
+    case 1: l1<1, L5, 16>(w, oy, ox, out, H, W, st); break;
+    case 2: l1<1, L6, 16>(w, oy, ox, out, H, W, st); break;
+    case 3: l1<1, L8, 16>(w, oy, ox, out, H, W, st); break;
+    case 4: l1<2, L4, 16>(w, oy, ox, out, H, W, st); break;
+    case 5: l1<2, L5, 16>(w, oy, ox, out, H, W, st); break;
+    case 6: l1<2, L8, 16>(w, oy, ox, out, H, W, st); break;
+    case 7: l1<3, L4, 16>(w, oy, ox, out, H, W, st); break;
+    case 8: l1<3, L8, 16>(w, oy, ox, out, H, W, st); break;
+    case 9: l1<4, L4, 16>(w, oy, ox, out, H, W, st); break;
+    case 10: l4<1, L4, 16>(w, oy, ox, out, H, W, st); break;
+    case 11: l4<1, L8, 16>(w, oy, ox, out, H, W, st); break;
+    case 12: l4<2, L4, 16>(w, oy, ox, out, H, W, st); break;
+    case 13: l4<1, L4, 8>(w, oy, ox, out, H, W, st); break;
+    case 14: l4<1, L8, 8>(w, oy, ox, out, H, W, st); break;
+    case 15: l1<2, L4, 32>(w, oy, ox, out, H, W, st); break;
+    case 16: l1<2, L4, 8>(w, oy, ox, out, H, W, st); break;
+    case 17: l1<1, L4, 4>(w, oy, ox, out, H, W, st); break;
+    case 18: l1<1, L8, 4>(w, oy, ox, out, H, W, st); break;
+    case 19: hipLaunchKernelGGL((stream_persist<1, L4>), dim3(1024), dim3(64, 4), 0, st, w, oy, ox, out, H, W); break;
+    case 20: hipLaunchKernelGGL((stream_persist<1, L8>), dim3(2048), dim3(64, 4), 0, st, w, oy, ox, out, H, W); break;
+    case 21: hipLaunchKernelGGL((stream_persist<1, L4>), dim3(768), dim3(64, 4), 0, st, w, oy, ox, out, H, W); break;
+    case 22: hipLaunchKernelGGL((stream_persist<1, L4>), dim3(512), dim3(64, 4), 0, st, w, oy, ox, out, H, W); break;
+    default: return -1;
+    }
+    return (int)hipGetLastError();
+}
