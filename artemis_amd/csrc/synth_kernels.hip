@@ -71,7 +71,10 @@ __device__ __forceinline__ TapIdx tap_index(const Geom &g, float a, float b, int
 
 // Forward for one pixel, channels [c0, c0 + CH).  wp/ap/bp point at tap 0 of this pixel,
 // ip at channel c0 of this sample's frame, op at channel c0 of this pixel's output.
-template <int CH>
+// KS > 0 fixes the filter size at compile time: a tap row's loads and gathers are then issued
+// together (the LDS kernels' fix-up runs this with one or two lanes active, so only the length of
+// the dependent-latency chain matters: 2 round trips per tap row instead of 2 per tap).
+template <int CH, int KS = 0>
 __device__ __forceinline__ void fwd_pixel_direct(const float *__restrict__ ip,
                                                  const float *__restrict__ wp,
                                                  const float *__restrict__ ap,
@@ -79,12 +82,15 @@ __device__ __forceinline__ void fwd_pixel_direct(const float *__restrict__ ip,
                                                  float *__restrict__ op, const Geom &g, int y, int x)
 {
     const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
+    const int k = KS > 0 ? KS : g.k;
     float acc[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) acc[c] = 0.f;
-    for (int r = 0; r < g.k; ++r) {
-        for (int s = 0; s < g.k; ++s) {
-            const size_t t = (size_t)(r * g.k + s) * plane;
+#pragma unroll 1
+    for (int r = 0; r < k; ++r) {
+#pragma unroll
+        for (int s = 0; s < k; ++s) {
+            const size_t t = (size_t)(r * k + s) * plane;
             const float wv = wp[t], a = ap[t], b = bp[t];
             const TapIdx ti = tap_index(g, a, b, y + g.oy0 + r * g.d, x + g.ox0 + s * g.d);
             const float ga = 1.f - ti.fa, gb = 1.f - ti.fb;
@@ -100,7 +106,7 @@ __device__ __forceinline__ void fwd_pixel_direct(const float *__restrict__ ip,
     for (int c = 0; c < CH; ++c) op[(size_t)c * plane] = acc[c];
 }
 
-template <int CH>
+template <int CH, int KS>
 __global__ __launch_bounds__(256) void synth_fwd_direct(const float *__restrict__ in,
                                                          const float *__restrict__ w,
                                                          const float *__restrict__ oy,
@@ -114,12 +120,14 @@ __global__ __launch_bounds__(256) void synth_fwd_direct(const float *__restrict_
     const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
     const size_t pix = (size_t)y * g.W + x;
     const size_t tb = (size_t)n * g.k * g.k * plane + pix;
-    fwd_pixel_direct<CH>(in + ((size_t)n * g.C + c0) * iplane, w + tb, oy + tb, ox + tb,
+    fwd_pixel_direct<CH, KS>(in + ((size_t)n * g.C + c0) * iplane, w + tb, oy + tb, ox + tb,
                          out + ((size_t)n * g.C + c0) * plane + pix, g, y, x);
 }
 
-// Fused gradWeight / gradOffset_y / gradOffset_x for one pixel, all C channels (run-time loop).
-// gwp/goyp/goxp point at tap 0 of this pixel (each may be null), gp at channel 0 of gradOutput.
+// Fused gradWeight / gradOffset_y / gradOffset_x for one pixel, all C channels (run-time loop
+// unless CH > 0).  gwp/goyp/goxp point at tap 0 of this pixel (each may be null), gp at channel 0
+// of gradOutput.  KS as in fwd_pixel_direct.
+template <int CH = 0, int KS = 0>
 __device__ __forceinline__ void bwd_pixel_direct(const float *__restrict__ ip,
                                                  const float *__restrict__ wp,
                                                  const float *__restrict__ ap,
@@ -130,14 +138,19 @@ __device__ __forceinline__ void bwd_pixel_direct(const float *__restrict__ ip,
                                                  int x)
 {
     const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
-    for (int r = 0; r < g.k; ++r) {
-        for (int s = 0; s < g.k; ++s) {
-            const size_t t = (size_t)(r * g.k + s) * plane;
+    const int k = KS > 0 ? KS : g.k;
+    const int C = CH > 0 ? CH : g.C;
+#pragma unroll 1
+    for (int r = 0; r < k; ++r) {
+#pragma unroll
+        for (int s = 0; s < k; ++s) {
+            const size_t t = (size_t)(r * k + s) * plane;
             const float a = ap[t], b = bp[t];
             const TapIdx ti = tap_index(g, a, b, y + g.oy0 + r * g.d, x + g.ox0 + s * g.d);
             // channel-reduced corner sums: P_q = sum_c delta_c * corner_q(c)
             float pbl = 0.f, ptl = 0.f, pbr = 0.f, ptr_ = 0.f;
-            for (int c = 0; c < g.C; ++c) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
                 const float dl = gp[(size_t)c * plane];
                 const float *p = ip + (size_t)c * iplane;
                 pbl += dl * p[ti.bl];
@@ -145,17 +158,20 @@ __device__ __forceinline__ void bwd_pixel_direct(const float *__restrict__ ip,
                 pbr += dl * p[ti.br];
                 ptr_ += dl * p[ti.tr];
             }
-            const float fa = ti.fa, fb = ti.fb, ga = 1.f - fa, gb = 1.f - fb;
-            if (gwp) gwp[t] = pbl * (ga * gb) + ptl * (fa * gb) + pbr * (ga * fb) + ptr_ * (fa * fb);
+            const float fa = ti.fa, fb = ti.fb;
+            const float dlt = ptl - pbl, drt = ptr_ - pbr;
+            const float lft = pbl + fa * dlt, rgt = pbr + fa * drt, across = rgt - lft;
+            if (gwp) gwp[t] = lft + fb * across;
             if (goyp || goxp) {
                 const float wv = wp[t];
-                if (goyp) goyp[t] = wv * ((ptl - pbl) * gb + (ptr_ - pbr) * fb);
-                if (goxp) goxp[t] = wv * ((pbr - pbl) * ga + (ptr_ - ptl) * fa);
+                if (goyp) goyp[t] = wv * (dlt + fb * (drt - dlt));
+                if (goxp) goxp[t] = wv * across;
             }
         }
     }
 }
 
+template <int CH, int KS>
 __global__ __launch_bounds__(256) void synth_bwd_direct(const float *__restrict__ in,
                                                          const float *__restrict__ w,
                                                          const float *__restrict__ oy,
@@ -172,7 +188,7 @@ __global__ __launch_bounds__(256) void synth_bwd_direct(const float *__restrict_
     const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
     const size_t pix = (size_t)y * g.W + x;
     const size_t tb = (size_t)n * g.k * g.k * plane + pix;
-    bwd_pixel_direct(in + (size_t)n * g.C * iplane, w + tb, oy + tb, ox + tb,
+    bwd_pixel_direct<CH, KS>(in + (size_t)n * g.C * iplane, w + tb, oy + tb, ox + tb,
                      gout + (size_t)n * g.C * plane + pix, gw ? gw + tb : nullptr,
                      goy ? goy + tb : nullptr, gox ? gox + tb : nullptr, g, y, x);
 }
@@ -314,7 +330,23 @@ constexpr int kTW = 64;
 // address_space(3) pointer: with a generic pointer hipcc merges the LDS read and the global
 // fallback into one flat_load per dword (select of pointers), which kills the design.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+
+// compile-time loop: the body receives std::integral_constant-like tags so that the tap index
+// can be a template argument (immediate LDS offsets)
+template <int V>
+struct IntTag {
+    static constexpr int value = V;
+};
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (B < E) {
+        f(IntTag<B>{});
+        static_for<B + 1, E>(f);
+    }
+}
 
 template <int R, int TH>
 struct TileShape {
@@ -506,7 +538,7 @@ __global__ __launch_bounds__(256, 4) void synth_fwd_tiled(const float *__restric
         st_stream(orow + (unsigned)x, acc0);
         st_stream(orow + plane + (unsigned)x, acc1);
         st_stream(orow + 2 * plane + (unsigned)x, acc2);
-        if (bad) fwd_pixel_direct<3>(ip, wrow + x, arow + x, brow + x, orow + x, g, y, x);
+        if (bad) fwd_pixel_direct<3, 5>(ip, wrow + x, arow + x, brow + x, orow + x, g, y, x);
         if (!more) break;
         rowoff += (size_t)4 * g.W;
     }
@@ -588,12 +620,92 @@ __global__ __launch_bounds__(256, 4) void synth_bwd_tiled(const float *__restric
             cur = nxt;
         }
         if (bad)
-            bwd_pixel_direct(ip, wrow + x, arow + x, brow + x, grow + x,
+            bwd_pixel_direct<3, 5>(ip, wrow + x, arow + x, brow + x, grow + x,
                              gw ? gw + rowoff + x : nullptr, goy ? goy + rowoff + x : nullptr,
                              gox ? gox + rowoff + x : nullptr, g, y, x);
         if (!more) break;
         rowoff += (size_t)4 * g.W;
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Cooperative fix-up (k = 5, d = 1, C = 3).  A pixel whose taps may leave the staged tile is
+// recomputed through clamped global gathers.  Such pixels are rare (a few dozen per 1080p frame
+// at sigma = 1) but a lane that walks its 25 taps alone pays ~50 dependent memory round trips at
+// the very end of its workgroup, and the launch cannot end before the slowest workgroup: measured,
+// that tail cost 8 us (forward) to 50 us (backward) per launch.  Here the whole wave recomputes
+// one flagged pixel at a time, lane l < 25 owning tap l: two round trips per pixel.
+// All 64 lanes must be active (the tap-major kernels never retire single lanes).
+// ------------------------------------------------------------------------------------------
+
+constexpr int kCoopMaxPixels = 12;  // more flagged lanes than this: every lane fixes its own pixel
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// wb/ab/bb: tap 0 of the sample's planes; ip: the sample's frame; on: the sample's output planes
+__device__ __forceinline__ void fwd_pixel_coop(const float *__restrict__ ip, const float *__restrict__ wb,
+                                            const float *__restrict__ ab,
+                                            const float *__restrict__ bb, float *__restrict__ on,
+                                            const Geom &g, int y, int xs)
+{
+    const int l = threadIdx.x & 63;
+    const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
+    const size_t pix = (size_t)y * g.W + xs;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    if (l < 25) {
+        const size_t o = (size_t)l * plane + pix;
+        const float wv = wb[o], a = ab[o], b = bb[o];
+        const int r = l / 5, s = l - 5 * r;
+        const TapIdx ti = tap_index(g, a, b, y + g.oy0 + r, xs + g.ox0 + s);
+        const float ga = 1.f - ti.fa, gb = 1.f - ti.fb;
+        const float c00 = ga * gb, c10 = ti.fa * gb, c01 = ga * ti.fb, c11 = ti.fa * ti.fb;
+        const float *p0 = ip, *p1 = ip + iplane, *p2 = ip + 2 * iplane;
+        c0 = wv * (p0[ti.bl] * c00 + p0[ti.tl] * c10 + p0[ti.br] * c01 + p0[ti.tr] * c11);
+        c1 = wv * (p1[ti.bl] * c00 + p1[ti.tl] * c10 + p1[ti.br] * c01 + p1[ti.tr] * c11);
+        c2 = wv * (p2[ti.bl] * c00 + p2[ti.tl] * c10 + p2[ti.br] * c01 + p2[ti.tr] * c11);
+    }
+    c0 = wave_sum(c0);
+    c1 = wave_sum(c1);
+    c2 = wave_sum(c2);
+    if (l == 0) {
+        on[pix] = c0;
+        on[plane + pix] = c1;
+        on[2 * plane + pix] = c2;
+    }
+}
+
+// gn: the sample's gradOutput planes; gwn/goyn/goxn: tap 0 of the sample's gradient planes (or null)
+__device__ __forceinline__ void bwd_pixel_coop(const float *__restrict__ ip, const float *__restrict__ wb,
+                                            const float *__restrict__ ab,
+                                            const float *__restrict__ bb,
+                                            const float *__restrict__ gn, float *__restrict__ gwn,
+                                            float *__restrict__ goyn, float *__restrict__ goxn,
+                                            const Geom &g, int y, int xs)
+{
+    const int l = threadIdx.x & 63;
+    if (l >= 25) return;
+    const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
+    const size_t pix = (size_t)y * g.W + xs;
+    const size_t o = (size_t)l * plane + pix;
+    const float wv = wb[o], a = ab[o], b = bb[o];
+    const float d0 = gn[pix], d1 = gn[plane + pix], d2 = gn[2 * plane + pix];
+    const int r = l / 5, s = l - 5 * r;
+    const TapIdx ti = tap_index(g, a, b, y + g.oy0 + r, xs + g.ox0 + s);
+    const float *p0 = ip, *p1 = ip + iplane, *p2 = ip + 2 * iplane;
+    const float pbl = d0 * p0[ti.bl] + d1 * p1[ti.bl] + d2 * p2[ti.bl];
+    const float ptl = d0 * p0[ti.tl] + d1 * p1[ti.tl] + d2 * p2[ti.tl];
+    const float pbr = d0 * p0[ti.br] + d1 * p1[ti.br] + d2 * p2[ti.br];
+    const float ptr_ = d0 * p0[ti.tr] + d1 * p1[ti.tr] + d2 * p2[ti.tr];
+    const float dlt = ptl - pbl, drt = ptr_ - pbr;
+    const float lft = pbl + ti.fa * dlt, rgt = pbr + ti.fa * drt, across = rgt - lft;
+    if (gwn) gwn[o] = lft + ti.fb * across;
+    if (goyn) goyn[o] = wv * (dlt + ti.fb * (drt - dlt));
+    if (goxn) goxn[o] = wv * across;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -617,8 +729,8 @@ struct TapCol {
     float w[ROWS], a[ROWS], b[ROWS];
 };
 
-// wbase/abase/bbase: wave-uniform pointers to (tap 0, row of j = 0, x = 0) of this sample;
-// rowstep[j] is folded by the caller into `roff[j]` (uniform element offsets of the rows).
+// wbase/abase/bbase: wave-uniform pointers to tap 0 of this sample; roff[j]: uniform element
+// offsets of the wave's rows.  Uniform base + 32-bit lane offset -> saddr addressing.
 template <int ROWS>
 __device__ __forceinline__ void load_tap_col(TapCol<ROWS> &t, const float *__restrict__ wbase,
                                              const float *__restrict__ abase,
@@ -634,14 +746,79 @@ __device__ __forceinline__ void load_tap_col(TapCol<ROWS> &t, const float *__res
     }
 }
 
-template <int R, int ROWS, int OCC>
-__global__ __launch_bounds__(256, OCC) void synth_fwd_tapmajor(const float *__restrict__ in,
-                                                                const float *__restrict__ w,
-                                                                const float *__restrict__ oy,
-                                                                const float *__restrict__ ox,
-                                                                float *__restrict__ out, Geom g)
+// Stage the clamped frame tile.  Texels are fetched in batches of kFillBatch per lane with all of
+// a batch's loads issued before the first LDS write: left to itself hipcc waits vmcnt(0) after
+// every texel, which serialises ~14 L2 round trips (~10 us) at the head of every workgroup.
+constexpr int kFillBatch = 7;
+
+template <int R, int TH, int THREADS>
+__device__ __forceinline__ void fill_tile_n(f32x4 *tile, const float *__restrict__ ip, const Geom &g,
+                                            int gy0, int gx0, int tid)
 {
-    constexpr int TH = 4 * ROWS;
+    constexpr int LW = TileShape<R, TH>::LW, LH = TileShape<R, TH>::LH;
+    constexpr int N = LH * LW;
+    const int iplane = g.Hin * g.Win;
+#pragma unroll 1
+    for (int base = tid; base < N; base += THREADS * kFillBatch) {
+        float c0[kFillBatch], c1[kFillBatch], c2[kFillBatch];
+#pragma unroll
+        for (int u = 0; u < kFillBatch; ++u) {
+            const int i = min(base + u * THREADS, N - 1);  // tail lanes re-fetch the last texel
+            const int ly = i / LW, lx = i - ly * LW;
+            const int gy = clampi(gy0 + ly, 0, g.Hin - 1), gx = clampi(gx0 + lx, 0, g.Win - 1);
+            const int o = gy * g.Win + gx;
+            c0[u] = ip[o];
+            c1[u] = ip[(size_t)iplane + o];
+            c2[u] = ip[2 * (size_t)iplane + o];
+        }
+#pragma unroll
+        for (int u = 0; u < kFillBatch; ++u) {
+            const int i = min(base + u * THREADS, N - 1);
+            tile[i] = f32x4{c0[u], c1[u], c2[u], 0.f};
+        }
+    }
+}
+
+// Byte address (within the tile) of the bottom-left texel of a tap's footprint:
+//   ((py + r + R + ia) * LW + (px + s + R + ib)) * 16
+//       = ia * (LW*16) + ib * 16 + rowbase + TAPOFF*16
+// rowbase = ((py + R) * LW + px + R) * 16 is one VGPR per row, set up once; the tap's own
+// displacement TAPOFF = r * LW + s is a compile-time constant that rides in the ds_read
+// immediate offset, so a tap costs v_mad_i32_i24 + v_lshl_add_u32 + v_min_u32.
+// The unsigned min keeps the four reads in bounds whatever the offsets are (a negative address
+// is a huge unsigned); a tap that really is outside is caught by the |offset| test below.
+template <int R, int TH, int TAPOFF>
+__device__ __forceinline__ Corners tile_corners_at(const lds_f32x4 *tile, int ia, int ib,
+                                                   int rowbase)
+{
+    constexpr int LW = TileShape<R, TH>::LW, LH = TileShape<R, TH>::LH;
+    const unsigned addr = (unsigned)(__mul24(ia, LW * 16) + rowbase + (ib << 4));
+    const unsigned safe = min(addr, (unsigned)(((LH - 1) * LW - 2 - TAPOFF) * 16));
+    const lds_f32x4 *p =
+        (const lds_f32x4 *)((const __attribute__((address_space(3))) char *)tile + safe);
+    Corners q;
+    q.bl = p[TAPOFF];
+    q.br = p[TAPOFF + 1];
+    q.tl = p[TAPOFF + LW];
+    q.tr = p[TAPOFF + LW + 1];
+    return q;
+}
+
+// |offset| < R + 1  =>  |trunc(offset)| <= R  =>  the footprint of every tap of every row of the
+// tile lies inside the staged tile.  One v_max3_f32 (with |.| source modifiers) per tap keeps the
+// running maximum; the comparison is made once per pixel.  NaN offsets truncate to 0 and stay in
+// the tile, so max's NaN-ignoring behaviour is the right one; +-inf is caught.
+__device__ __forceinline__ float track_abs(float m, float a, float b)
+{
+    return fmaxf(m, fmaxf(fabsf(a), fabsf(b)));
+}
+
+template <int R, int WAVES, int ROWS, int OCC>
+__global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
+    const float *__restrict__ in, const float *__restrict__ w, const float *__restrict__ oy,
+    const float *__restrict__ ox, float *__restrict__ out, Geom g)
+{
+    constexpr int TH = WAVES * ROWS;
     constexpr int LW = TileShape<R, TH>::LW, LH = TileShape<R, TH>::LH;
     __shared__ f32x4 tile[LH * LW];
     const lds_f32x4 *ltile = (const lds_f32x4 *)tile;
@@ -650,8 +827,11 @@ __global__ __launch_bounds__(256, OCC) void synth_fwd_tapmajor(const float *__re
     const int tid = wy * 64 + threadIdx.x;
     const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
     const float *ip = in + (size_t)n * 3 * iplane;
-    const int px = threadIdx.x, x = tx0 + px;
-    const bool active = x < g.W && ty0 + wy < g.H;
+    // A lane past the right edge acts as the last image column (same operands, same arithmetic,
+    // same stores as that column's owner), like the rows below: no lane ever retires on its own,
+    // so wave-wide operations in the fix-up see all 64 lanes.
+    const int x = min(tx0 + (int)threadIdx.x, g.W - 1), px = x - tx0;
+    const bool active = ty0 + wy < g.H;  // wave-uniform
     const float *wb = w + (size_t)n * 25 * plane, *ab = oy + (size_t)n * 25 * plane,
                 *bb = ox + (size_t)n * 25 * plane;
 
@@ -662,27 +842,31 @@ __global__ __launch_bounds__(256, OCC) void synth_fwd_tapmajor(const float *__re
     size_t roff[ROWS];
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) {
-        rowy[j] = min(ty0 + wy + 4 * j, g.H - 1);
+        rowy[j] = min(ty0 + wy + WAVES * j, g.H - 1);
         roff[j] = (size_t)rowy[j] * g.W;
     }
 
+    // first tap of this lane's pixels: issued before the tile fill so the stream is already in
+    // flight while the tile is staged
     TapCol<ROWS> cur;
     if (active) load_tap_col<ROWS>(cur, wb, ab, bb, plane, 0, roff, (unsigned)x);
 
-    fill_tile<R, TH>(tile, ip, g, ty0 + g.oy0 - R, tx0 + g.ox0 - R, tid);
+    fill_tile_n<R, TH, 64 * WAVES>(tile, ip, g, ty0 + g.oy0 - R, tx0 + g.ox0 - R, tid);
     __syncthreads();
     if (!active) return;
 
-    float acc[ROWS][3];
-    unsigned mly[ROWS], mlx[ROWS];
+    int rowbase[ROWS];
+    float acc0[ROWS], acc1[ROWS], acc2[ROWS];
+    float mabs[ROWS];
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) {
-        acc[j][0] = acc[j][1] = acc[j][2] = 0.f;
-        mly[j] = mlx[j] = 0;
+        rowbase[j] = ((rowy[j] - ty0 + R) * LW + px + R) * 16;
+        acc0[j] = acc1[j] = acc2[j] = 0.f;
+        mabs[j] = 0.f;
     }
-#pragma unroll
-    for (int t = 0; t < 25; ++t) {
-        const int r = t / 5, s = t % 5;
+    static_for<0, 25>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        constexpr int r = t / 5, s = t % 5;
         TapCol<ROWS> nxt;
         if (t < 24) load_tap_col<ROWS>(nxt, wb, ab, bb, plane, t + 1, roff, (unsigned)x);
         __builtin_amdgcn_sched_barrier(0);
@@ -691,47 +875,60 @@ __global__ __launch_bounds__(256, OCC) void synth_fwd_tapmajor(const float *__re
             const float wv = cur.w[j], a = cur.a[j], b = cur.b[j];
             const int ia = (int)a, ib = (int)b;
             const float fa = a - (float)ia, fb = b - (float)ib;
-            const Corners q = tile_corners_max<R, TH>(ltile, wadd(rowy[j] - ty0 + r + R, ia),
-                                                      wadd(px + s + R, ib), mly[j], mlx[j]);
+            mabs[j] = track_abs(mabs[j], a, b);
+            const Corners q = tile_corners_at<R, TH, r * LW + s>(ltile, ia, ib, rowbase[j]);
             const float ga = 1.f - fa, gb = 1.f - fb;
             const float c00 = ga * gb, c10 = fa * gb, c01 = ga * fb, c11 = fa * fb;
-            acc[j][0] += wv * (q.bl.x * c00 + q.tl.x * c10 + q.br.x * c01 + q.tr.x * c11);
-            acc[j][1] += wv * (q.bl.y * c00 + q.tl.y * c10 + q.br.y * c01 + q.tr.y * c11);
-            acc[j][2] += wv * (q.bl.z * c00 + q.tl.z * c10 + q.br.z * c01 + q.tr.z * c11);
+            acc0[j] += wv * (q.bl.x * c00 + q.tl.x * c10 + q.br.x * c01 + q.tr.x * c11);
+            acc1[j] += wv * (q.bl.y * c00 + q.tl.y * c10 + q.br.y * c01 + q.tr.y * c11);
+            acc2[j] += wv * (q.bl.z * c00 + q.tl.z * c10 + q.br.z * c01 + q.tr.z * c11);
             // pin the arithmetic in place (see synth_fwd_tiled) and bound the LDS results in
             // flight to kRowGroup rows (16 VGPRs each)
-            asm volatile("" : "+v"(acc[j][0]), "+v"(acc[j][1]), "+v"(acc[j][2]), "+v"(mly[j]),
-                         "+v"(mlx[j]));
+            asm volatile("" : "+v"(acc0[j]), "+v"(acc1[j]), "+v"(acc2[j]), "+v"(mabs[j]));
             if (j % kRowGroup == kRowGroup - 1) __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_sched_barrier(0);
         cur = nxt;
-    }
+    });
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) {
-        const int y = rowy[j];
         float *orow = out + (size_t)n * 3 * plane + roff[j];
-        st_stream(orow + (unsigned)x, acc[j][0]);
-        st_stream(orow + plane + (unsigned)x, acc[j][1]);
-        st_stream(orow + 2 * plane + (unsigned)x, acc[j][2]);
-        if (tile_missed<R, TH>(mly[j], mlx[j])) {
-            const size_t o = roff[j] + x;
-            fwd_pixel_direct<3>(ip, wb + o, ab + o, bb + o, orow + x, g, y, x);
+        st_stream(orow + (unsigned)x, acc0[j]);
+        st_stream(orow + plane + (unsigned)x, acc1[j]);
+        st_stream(orow + 2 * plane + (unsigned)x, acc2[j]);
+        // some tap may have left the tile: recompute the pixel through the direct path
+        const bool flag = !(mabs[j] < (float)(R + 1));
+        unsigned long long todo = __ballot(flag && tx0 + (int)threadIdx.x == x);
+        if (todo) {  // wave-uniform, rare
+            if (__popcll(todo) <= kCoopMaxPixels) {
+                while (todo) {
+                    const int b = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    fwd_pixel_coop(ip, wb, ab, bb, out + (size_t)n * 3 * plane, g, rowy[j], tx0 + b);
+                }
+            } else if (flag) {
+                const size_t o = roff[j] + x;
+                fwd_pixel_direct<3, 5>(ip, wb + o, ab + o, bb + o, orow + x, g, rowy[j], x);
+            }
         }
     }
 }
 
-template <int R, int ROWS, int OCC, bool ALL>
-__global__ __launch_bounds__(256, OCC) void synth_bwd_tapmajor(const float *__restrict__ in,
-                                                                const float *__restrict__ w,
-                                                                const float *__restrict__ oy,
-                                                                const float *__restrict__ ox,
-                                                                const float *__restrict__ gout,
-                                                                float *__restrict__ gw,
-                                                                float *__restrict__ goy,
-                                                                float *__restrict__ gox, Geom g)
+// ALL: the three gradients are all requested (the model's case).
+// Per tap, with P_q = sum_c gradOut_c * corner_q(c)  (q = bl, tl, br, tr):
+//   L = P_bl + fa (P_tl - P_bl),  Rt = P_br + fa (P_tr - P_br)      (vertical lerps)
+//   gradWeight   = L + fb (Rt - L)
+//   gradOffset_x = w (Rt - L)                                        (= d/d beta of the blend)
+//   gradOffset_y = w ((P_tl - P_bl) + fb ((P_tr - P_br) - (P_tl - P_bl)))
+// which is the reference's formulas (cupy_module/synth.py:90-95, :140-145, :190-195) with the
+// common subexpressions shared: 22 flops per tap instead of 32.
+template <int R, int WAVES, int ROWS, int OCC, bool ALL>
+__global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
+    const float *__restrict__ in, const float *__restrict__ w, const float *__restrict__ oy,
+    const float *__restrict__ ox, const float *__restrict__ gout, float *__restrict__ gw,
+    float *__restrict__ goy, float *__restrict__ gox, Geom g)
 {
-    constexpr int TH = 4 * ROWS;
+    constexpr int TH = WAVES * ROWS;
     constexpr int LW = TileShape<R, TH>::LW, LH = TileShape<R, TH>::LH;
     __shared__ f32x4 tile[LH * LW];
     const lds_f32x4 *ltile = (const lds_f32x4 *)tile;
@@ -740,8 +937,9 @@ __global__ __launch_bounds__(256, OCC) void synth_bwd_tapmajor(const float *__re
     const int tid = wy * 64 + threadIdx.x;
     const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
     const float *ip = in + (size_t)n * 3 * iplane;
-    const int px = threadIdx.x, x = tx0 + px;
-    const bool active = x < g.W && ty0 + wy < g.H;
+    // lanes past the right edge duplicate the last image column (see forward)
+    const int x = min(tx0 + (int)threadIdx.x, g.W - 1), px = x - tx0;
+    const bool active = ty0 + wy < g.H;  // wave-uniform
     const size_t nb = (size_t)n * 25 * plane;
     const float *wb = w + nb, *ab = oy + nb, *bb = ox + nb;
 
@@ -749,30 +947,32 @@ __global__ __launch_bounds__(256, OCC) void synth_bwd_tapmajor(const float *__re
     size_t roff[ROWS];
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) {
-        rowy[j] = min(ty0 + wy + 4 * j, g.H - 1);
+        rowy[j] = min(ty0 + wy + WAVES * j, g.H - 1);
         roff[j] = (size_t)rowy[j] * g.W;
     }
 
     TapCol<ROWS> cur;
     if (active) load_tap_col<ROWS>(cur, wb, ab, bb, plane, 0, roff, (unsigned)x);
 
-    fill_tile<R, TH>(tile, ip, g, ty0 + g.oy0 - R, tx0 + g.ox0 - R, tid);
+    fill_tile_n<R, TH, 64 * WAVES>(tile, ip, g, ty0 + g.oy0 - R, tx0 + g.ox0 - R, tid);
     __syncthreads();
     if (!active) return;
 
+    int rowbase[ROWS];
     float d[ROWS][3];
-    unsigned mly[ROWS], mlx[ROWS];
+    float mabs[ROWS];
     const float *gb_ = gout + (size_t)n * 3 * plane;
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) {
+        rowbase[j] = ((rowy[j] - ty0 + R) * LW + px + R) * 16;
         d[j][0] = ld_stream(gb_ + roff[j] + (unsigned)x);
         d[j][1] = ld_stream(gb_ + plane + roff[j] + (unsigned)x);
         d[j][2] = ld_stream(gb_ + 2 * plane + roff[j] + (unsigned)x);
-        mly[j] = mlx[j] = 0;
+        mabs[j] = 0.f;
     }
-#pragma unroll
-    for (int t = 0; t < 25; ++t) {
-        const int r = t / 5, s = t % 5;
+    static_for<0, 25>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        constexpr int r = t / 5, s = t % 5;
         TapCol<ROWS> nxt;
         if (t < 24) load_tap_col<ROWS>(nxt, wb, ab, bb, plane, t + 1, roff, (unsigned)x);
         __builtin_amdgcn_sched_barrier(0);
@@ -781,34 +981,44 @@ __global__ __launch_bounds__(256, OCC) void synth_bwd_tapmajor(const float *__re
             const float wv = cur.w[j], a = cur.a[j], b = cur.b[j];
             const int ia = (int)a, ib = (int)b;
             const float fa = a - (float)ia, fb = b - (float)ib;
-            const Corners q = tile_corners_max<R, TH>(ltile, wadd(rowy[j] - ty0 + r + R, ia),
-                                                      wadd(px + s + R, ib), mly[j], mlx[j]);
+            mabs[j] = track_abs(mabs[j], a, b);
+            const Corners q = tile_corners_at<R, TH, r * LW + s>(ltile, ia, ib, rowbase[j]);
             const float pbl = d[j][0] * q.bl.x + d[j][1] * q.bl.y + d[j][2] * q.bl.z;
             const float ptl = d[j][0] * q.tl.x + d[j][1] * q.tl.y + d[j][2] * q.tl.z;
             const float pbr = d[j][0] * q.br.x + d[j][1] * q.br.y + d[j][2] * q.br.z;
             const float ptr_ = d[j][0] * q.tr.x + d[j][1] * q.tr.y + d[j][2] * q.tr.z;
-            const float ga = 1.f - fa, gb = 1.f - fb;
+            const float dl = ptl - pbl, dr = ptr_ - pbr;
+            const float lft = pbl + fa * dl, rgt = pbr + fa * dr;
+            const float across = rgt - lft;
             const size_t o = nb + (size_t)t * plane + roff[j];
-            if (ALL || gw)
-                st_stream(gw + o + (unsigned)x, pbl * (ga * gb) + ptl * (fa * gb) +
-                                                    pbr * (ga * fb) + ptr_ * (fa * fb));
-            if (ALL || goy)
-                st_stream(goy + o + (unsigned)x, wv * ((ptl - pbl) * gb + (ptr_ - pbr) * fb));
-            if (ALL || gox)
-                st_stream(gox + o + (unsigned)x, wv * ((pbr - pbl) * ga + (ptr_ - ptl) * fa));
-            asm volatile("" : "+v"(mly[j]), "+v"(mlx[j]));
+            if (ALL || gw) st_stream(gw + o + (unsigned)x, lft + fb * across);
+            if (ALL || goy) st_stream(goy + o + (unsigned)x, wv * (dl + fb * (dr - dl)));
+            if (ALL || gox) st_stream(gox + o + (unsigned)x, wv * across);
+            asm volatile("" : "+v"(mabs[j]));
             if (j % kRowGroup == kRowGroup - 1) __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_sched_barrier(0);
         cur = nxt;
-    }
+    });
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) {
-        const int y = rowy[j];
-        if (tile_missed<R, TH>(mly[j], mlx[j])) {
-            const size_t o = roff[j] + x;
-            bwd_pixel_direct(ip, wb + o, ab + o, bb + o, gb_ + o, gw ? gw + nb + o : nullptr,
-                             goy ? goy + nb + o : nullptr, gox ? gox + nb + o : nullptr, g, y, x);
+        const bool flag = !(mabs[j] < (float)(R + 1));
+        unsigned long long todo = __ballot(flag && tx0 + (int)threadIdx.x == x);
+        if (todo) {  // wave-uniform, rare
+            if (__popcll(todo) <= kCoopMaxPixels) {
+                while (todo) {
+                    const int b = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    bwd_pixel_coop(ip, wb, ab, bb, gb_, gw ? gw + nb : nullptr,
+                                   goy ? goy + nb : nullptr, gox ? gox + nb : nullptr, g, rowy[j],
+                                   tx0 + b);
+                }
+            } else if (flag) {
+                const size_t o = roff[j] + x;
+                bwd_pixel_direct<3, 5>(ip, wb + o, ab + o, bb + o, gb_ + o,
+                                       gw ? gw + nb + o : nullptr, goy ? goy + nb + o : nullptr,
+                                       gox ? gox + nb + o : nullptr, g, rowy[j], x);
+            }
         }
     }
 }
@@ -880,6 +1090,9 @@ int make_geom(Geom &g, int N, int C, int H, int W, int k, int d)
 #ifndef SYNTH_TAPMAJOR
 #define SYNTH_TAPMAJOR 1
 #endif
+#ifndef SYNTH_WAVES
+#define SYNTH_WAVES 4
+#endif
 #ifndef SYNTH_ROWS
 #define SYNTH_ROWS 8
 #endif
@@ -916,8 +1129,9 @@ void launch_fwd_tiled(const float *in, const float *w, const float *oy, const fl
                       const Geom &g, hipStream_t st)
 {
 #if SYNTH_TAPMAJOR
-    hipLaunchKernelGGL((synth_fwd_tapmajor<R, SYNTH_ROWS, SYNTH_OCC>), pixel_grid(g, 4 * SYNTH_ROWS),
-                       dim3(64, 4), 0, st, in, w, oy, ox, out, g);
+    hipLaunchKernelGGL((synth_fwd_tapmajor<R, SYNTH_WAVES, SYNTH_ROWS, SYNTH_OCC>),
+                       pixel_grid(g, SYNTH_WAVES * SYNTH_ROWS), dim3(64, SYNTH_WAVES), 0, st, in, w, oy,
+                       ox, out, g);
 #else
     hipLaunchKernelGGL((synth_fwd_tiled<R, kTileTH>), pixel_grid(g, kTileTH), dim3(64, 4), 0, st, in,
                        w, oy, ox, out, g);
@@ -931,13 +1145,13 @@ void launch_bwd_tiled(const float *in, const float *w, const float *oy, const fl
 {
 #if SYNTH_BWD_TAPMAJOR
     if (gw && goy && gox)
-        hipLaunchKernelGGL((synth_bwd_tapmajor<R, SYNTH_ROWS, SYNTH_OCC, true>),
-                           pixel_grid(g, 4 * SYNTH_ROWS), dim3(64, 4), 0, st, in, w, oy, ox, gout, gw,
-                           goy, gox, g);
+        hipLaunchKernelGGL((synth_bwd_tapmajor<R, SYNTH_WAVES, SYNTH_ROWS, SYNTH_OCC, true>),
+                           pixel_grid(g, SYNTH_WAVES * SYNTH_ROWS), dim3(64, SYNTH_WAVES), 0, st, in, w,
+                           oy, ox, gout, gw, goy, gox, g);
     else
-        hipLaunchKernelGGL((synth_bwd_tapmajor<R, SYNTH_ROWS, SYNTH_OCC, false>),
-                           pixel_grid(g, 4 * SYNTH_ROWS), dim3(64, 4), 0, st, in, w, oy, ox, gout, gw,
-                           goy, gox, g);
+        hipLaunchKernelGGL((synth_bwd_tapmajor<R, SYNTH_WAVES, SYNTH_ROWS, SYNTH_OCC, false>),
+                           pixel_grid(g, SYNTH_WAVES * SYNTH_ROWS), dim3(64, SYNTH_WAVES), 0, st, in, w,
+                           oy, ox, gout, gw, goy, gox, g);
 #else
     if (gw && goy && gox)
         hipLaunchKernelGGL((synth_bwd_tiled<R, kTileTH, true>), pixel_grid(g, kTileTH), dim3(64, 4), 0,
@@ -946,6 +1160,18 @@ void launch_bwd_tiled(const float *in, const float *w, const float *oy, const fl
         hipLaunchKernelGGL((synth_bwd_tiled<R, kTileTH, false>), pixel_grid(g, kTileTH), dim3(64, 4), 0,
                            st, in, w, oy, ox, gout, gw, goy, gox, g);
 #endif
+}
+
+template <int KS>
+void launch_fwd_direct(int ch, dim3 grid, dim3 block, hipStream_t st, const float *in, const float *w,
+                       const float *oy, const float *ox, float *out, const Geom &g, int c0)
+{
+    switch (ch) {
+    case 1: hipLaunchKernelGGL((synth_fwd_direct<1, KS>), grid, block, 0, st, in, w, oy, ox, out, g, c0); break;
+    case 2: hipLaunchKernelGGL((synth_fwd_direct<2, KS>), grid, block, 0, st, in, w, oy, ox, out, g, c0); break;
+    case 3: hipLaunchKernelGGL((synth_fwd_direct<3, KS>), grid, block, 0, st, in, w, oy, ox, out, g, c0); break;
+    default: hipLaunchKernelGGL((synth_fwd_direct<4, KS>), grid, block, 0, st, in, w, oy, ox, out, g, c0); break;
+    }
 }
 
 int count_bits_for(const Geom &g)
@@ -994,12 +1220,8 @@ int artemis_synth_forward(const float *input, const float *weight, const float *
         for (int c0 = 0; c0 < C; c0 += 4) {
             const int ch = C - c0 < 4 ? C - c0 : 4;
             const dim3 grid = pixel_grid(g, 4), block(64, 4);
-            switch (ch) {
-            case 1: hipLaunchKernelGGL(synth_fwd_direct<1>, grid, block, 0, st, input, weight, offset_y, offset_x, output, g, c0); break;
-            case 2: hipLaunchKernelGGL(synth_fwd_direct<2>, grid, block, 0, st, input, weight, offset_y, offset_x, output, g, c0); break;
-            case 3: hipLaunchKernelGGL(synth_fwd_direct<3>, grid, block, 0, st, input, weight, offset_y, offset_x, output, g, c0); break;
-            default: hipLaunchKernelGGL(synth_fwd_direct<4>, grid, block, 0, st, input, weight, offset_y, offset_x, output, g, c0); break;
-            }
+            if (k == 5) launch_fwd_direct<5>(ch, grid, block, st, input, weight, offset_y, offset_x, output, g, c0);
+            else launch_fwd_direct<0>(ch, grid, block, st, input, weight, offset_y, offset_x, output, g, c0);
         }
     }
     return check_launch("artemis_synth_forward");
@@ -1045,9 +1267,14 @@ int artemis_synth_backward(const float *input, const float *weight, const float 
         case 4: launch_bwd_tiled<4>(input, weight, offset_y, offset_x, grad_output, grad_weight, grad_offset_y, grad_offset_x, g, st); break;
         case 8: launch_bwd_tiled<8>(input, weight, offset_y, offset_x, grad_output, grad_weight, grad_offset_y, grad_offset_x, g, st); break;
         default:
-            hipLaunchKernelGGL(synth_bwd_direct, pixel_grid(g, 4), dim3(64, 4), 0, st, input, weight,
-                               offset_y, offset_x, grad_output, grad_weight, grad_offset_y,
-                               grad_offset_x, g);
+            if (k == 5 && C == 3)
+                hipLaunchKernelGGL((synth_bwd_direct<3, 5>), pixel_grid(g, 4), dim3(64, 4), 0, st, input,
+                                   weight, offset_y, offset_x, grad_output, grad_weight,
+                                   grad_offset_y, grad_offset_x, g);
+            else
+                hipLaunchKernelGGL((synth_bwd_direct<0, 0>), pixel_grid(g, 4), dim3(64, 4), 0, st, input,
+                                   weight, offset_y, offset_x, grad_output, grad_weight,
+                                   grad_offset_y, grad_offset_x, g);
         }
         const int e = check_launch("artemis_synth_backward (taps)");
         if (e) return e;
