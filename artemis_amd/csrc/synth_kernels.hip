@@ -194,6 +194,7 @@ __global__ __launch_bounds__(256) void synth_bwd_direct(const float *__restrict_
 }
 
 // gradInput, fp32 atomics straight to global memory (any k, d, C).  gin must be zeroed.
+template <int CH, int KS>
 __global__ __launch_bounds__(256) void synth_gin_atomic_direct(const float *__restrict__ w,
                                                                 const float *__restrict__ oy,
                                                                 const float *__restrict__ ox,
@@ -205,19 +206,22 @@ __global__ __launch_bounds__(256) void synth_gin_atomic_direct(const float *__re
     const int n = blockIdx.z;
     if (x >= g.W || y >= g.H) return;
     const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
-    const int K = g.k * g.k;
+    const int k = KS > 0 ? KS : g.k, C = CH > 0 ? CH : g.C;
     const size_t pix = (size_t)y * g.W + x;
-    const size_t tbase = (size_t)n * K * plane + pix;
-    float *op = gin + (size_t)n * g.C * iplane;
-    const float *gp = gout + (size_t)n * g.C * plane + pix;
-    for (int r = 0; r < g.k; ++r) {
-        for (int s = 0; s < g.k; ++s) {
-            const size_t t = tbase + (size_t)(r * g.k + s) * plane;
+    const size_t tbase = (size_t)n * k * k * plane + pix;
+    float *op = gin + (size_t)n * C * iplane;
+    const float *gp = gout + (size_t)n * C * plane + pix;
+#pragma unroll 1
+    for (int r = 0; r < k; ++r) {
+#pragma unroll
+        for (int s = 0; s < k; ++s) {
+            const size_t t = tbase + (size_t)(r * k + s) * plane;
             const float wv = w[t], a = oy[t], b = ox[t];
             const TapIdx ti = tap_index(g, a, b, y + g.oy0 + r * g.d, x + g.ox0 + s * g.d);
-            const float c00 = (1.f - ti.fa) * (1.f - ti.fb), c10 = ti.fa * (1.f - ti.fb);
-            const float c01 = (1.f - ti.fa) * ti.fb, c11 = ti.fa * ti.fb;
-            for (int c = 0; c < g.C; ++c) {
+            const float ga = 1.f - ti.fa, gb = 1.f - ti.fb;
+            const float c00 = ga * gb, c10 = ti.fa * gb, c01 = ga * ti.fb, c11 = ti.fa * ti.fb;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
                 const float dw = gp[(size_t)c * plane] * wv;
                 float *p = op + (size_t)c * iplane;
                 atomicAdd(p + ti.bl, dw * c00);
@@ -255,17 +259,28 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ v
     if ((threadIdx.x & 63) == 0) atomicMax(slot, m);
 }
 
-// log2 of the fixed-point scale; a pure function of the two maxima, identical in every lane
+// log2 of the fixed-point scale; a pure function of the two maxima, identical in every lane.
+// Every contribution  gradOut * w * coef  is bounded by m = 4 max|w| max|gradOut| < 2^e
+// (|coef| < 4: (1 + |fa|)(1 + |fb|) with |fa|, |fb| < 1), so scaled by 2^(30 - e) it rounds to an
+// int32 (one v_rndne + v_cvt; its 24-bit mantissa is all the precision the fp32 product has) and
+// is added, sign-extended, into a 64-bit integer.  count_bits bounds how many contributions can
+// meet in one element so that even that sum stays below 2^62.
 __device__ __forceinline__ int det_scale_log2(const unsigned *hdr, int count_bits)
 {
     const float mw = __uint_as_float(hdr[0]), mg = __uint_as_float(hdr[1]);
-    float m = 4.f * mw * mg;  // |coef| < 4: (1 +|fa|)(1 + |fb|) with |fa|,|fb| < 1
+    float m = 4.f * mw * mg;
     if (!(m > 0.f) || !(m < 3.0e38f)) return 0;
     int e;
     frexpf(m, &e);  // m < 2^e
-    return 62 - count_bits - e;
+    return min(30, 62 - count_bits) - e;
 }
 
+__device__ __forceinline__ unsigned long long to_fixed(float contrib_scaled)
+{
+    return (unsigned long long)(long long)(int)rintf(contrib_scaled);  // saturating, NaN -> 0
+}
+
+template <int CH, int KS>
 __global__ __launch_bounds__(256) void synth_gin_fixed_direct(const float *__restrict__ w,
                                                                const float *__restrict__ oy,
                                                                const float *__restrict__ ox,
@@ -277,28 +292,31 @@ __global__ __launch_bounds__(256) void synth_gin_fixed_direct(const float *__res
     const int y = blockIdx.y * 4 + threadIdx.y;
     const int n = blockIdx.z;
     if (x >= g.W || y >= g.H) return;
-    const double scale = ldexp(1.0, det_scale_log2((const unsigned *)ws, count_bits));
+    const float scale = ldexpf(1.f, det_scale_log2((const unsigned *)ws, count_bits));
     unsigned long long *accum = (unsigned long long *)(ws + kDetHeaderBytes);
     const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
-    const int K = g.k * g.k;
+    const int k = KS > 0 ? KS : g.k, C = CH > 0 ? CH : g.C;
     const size_t pix = (size_t)y * g.W + x;
-    const size_t tbase = (size_t)n * K * plane + pix;
-    unsigned long long *op = accum + (size_t)n * g.C * iplane;
-    const float *gp = gout + (size_t)n * g.C * plane + pix;
-    for (int r = 0; r < g.k; ++r) {
-        for (int s = 0; s < g.k; ++s) {
-            const size_t t = tbase + (size_t)(r * g.k + s) * plane;
+    const size_t tbase = (size_t)n * k * k * plane + pix;
+    unsigned long long *op = accum + (size_t)n * C * iplane;
+    const float *gp = gout + (size_t)n * C * plane + pix;
+#pragma unroll 1
+    for (int r = 0; r < k; ++r) {
+#pragma unroll
+        for (int s = 0; s < k; ++s) {
+            const size_t t = tbase + (size_t)(r * k + s) * plane;
             const float wv = w[t], a = oy[t], b = ox[t];
             const TapIdx ti = tap_index(g, a, b, y + g.oy0 + r * g.d, x + g.ox0 + s * g.d);
-            const float c00 = (1.f - ti.fa) * (1.f - ti.fb), c10 = ti.fa * (1.f - ti.fb);
-            const float c01 = (1.f - ti.fa) * ti.fb, c11 = ti.fa * ti.fb;
-            for (int c = 0; c < g.C; ++c) {
-                const double dw = (double)(gp[(size_t)c * plane] * wv) * scale;
+            const float ga = 1.f - ti.fa, gb = 1.f - ti.fb;
+            const float c00 = ga * gb, c10 = ti.fa * gb, c01 = ga * ti.fb, c11 = ti.fa * ti.fb;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float dw = gp[(size_t)c * plane] * wv * scale;
                 unsigned long long *p = op + (size_t)c * iplane;
-                atomicAdd(p + ti.bl, (unsigned long long)__double2ll_rn(dw * (double)c00));
-                atomicAdd(p + ti.tl, (unsigned long long)__double2ll_rn(dw * (double)c10));
-                atomicAdd(p + ti.br, (unsigned long long)__double2ll_rn(dw * (double)c01));
-                atomicAdd(p + ti.tr, (unsigned long long)__double2ll_rn(dw * (double)c11));
+                atomicAdd(p + ti.bl, to_fixed(dw * c00));
+                atomicAdd(p + ti.tl, to_fixed(dw * c10));
+                atomicAdd(p + ti.br, to_fixed(dw * c01));
+                atomicAdd(p + ti.tr, to_fixed(dw * c11));
             }
         }
     }
@@ -308,7 +326,7 @@ __global__ __launch_bounds__(256) void det_finalize_kernel(const unsigned char *
                                                             float *__restrict__ gin, size_t count,
                                                             int count_bits)
 {
-    const double inv = ldexp(1.0, -det_scale_log2((const unsigned *)ws, count_bits));
+    const double inv = ldexp(1.0, -det_scale_log2((const unsigned *)ws, count_bits));  // exact
     const long long *accum = (const long long *)(ws + kDetHeaderBytes);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
          i += (size_t)gridDim.x * blockDim.x)
@@ -1023,6 +1041,173 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// gradInput for k = 5, d = 1, C = 3, LDS-privatised.  (No reference counterpart: upstream returns
+// unfilled zeros, cupy_module/synth.py:333,391.)  The adjoint of the forward scatters, per tap,
+// gradOut_c * w * coef_q to the four clamped corners: 300 adds per pixel.  Straight to memory
+// that is 2.5 GB of float atomics per 1080p frame (>2 ms at the chip's ~1.3 TB/s atomic rate).
+// Here a workgroup accumulates its 64 x TH pixels into an LDS copy of the frame tile with
+// ds_add_u64 on fixed-point integers (planar [c][ly][lx]: a wave's lanes hit consecutive banks),
+// then flushes the tile with one global atomic per touched texel (~5 per pixel).  Taps displaced
+// beyond the tile radius are left out of the LDS pass and sent to memory individually afterwards
+// (same |offset| < R + 1 test in both passes, so every contribution lands exactly once).
+// FIXED (deterministic mode): the flush adds the integers into the int64 image of the workspace,
+// so the result does not depend on any order; otherwise each tile sum is converted to fp32 and
+// added to gradInput with float atomics.  Same tap-major streaming order as the other kernels.
+// ------------------------------------------------------------------------------------------
+
+// LDS accumulation is always 64-bit fixed point: ds_add_f32 turned out to execute lane-serially
+// on gfx950 (~170 cycles per wave instruction, measured: 3.1 ms per 1080p frame against 0.4 ms for
+// ds_add_u64), so even the non-deterministic mode sums integers on chip and only converts to
+// fp32 for the cross-workgroup adds.
+template <int R, int WAVES, int ROWS, bool FIXED>
+__global__ __launch_bounds__(64 * WAVES) void synth_gin_tiled(const float *__restrict__ w,
+                                                              const float *__restrict__ oy,
+                                                              const float *__restrict__ ox,
+                                                              const float *__restrict__ gout,
+                                                              float *__restrict__ gin,
+                                                              unsigned char *__restrict__ ws,
+                                                              Geom g, int count_bits)
+{
+    typedef unsigned long long acc_t;
+    constexpr int TH = WAVES * ROWS;
+    constexpr int LW = TileShape<R, TH>::LW, LH = TileShape<R, TH>::LH;
+    constexpr int CS = LH * LW;  // channel stride in the LDS tile
+    __shared__ acc_t acc[3 * CS];
+    const int tx0 = blockIdx.x * kTW, ty0 = blockIdx.y * TH, n = blockIdx.z;
+    const int wy = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int tid = wy * 64 + threadIdx.x;
+    const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
+    const int xr = tx0 + (int)threadIdx.x;          // this lane's own column
+    const bool lane_on = xr < g.W;                   // lanes past the right edge add nothing
+    const int x = min(xr, g.W - 1), px = x - tx0;
+    const size_t nb = (size_t)n * 25 * plane;
+    const float *wb = w + nb, *ab = oy + nb, *bb = ox + nb;
+    const float *gb_ = gout + (size_t)n * 3 * plane;
+
+    // ws: header with the two maxima (both modes) followed, in FIXED mode, by the int64 image
+    const int slog2 = det_scale_log2((const unsigned *)ws, count_bits);
+    const float scale = ldexpf(1.f, slog2);
+    acc_t *gfix = (acc_t *)((unsigned char *)ws + kDetHeaderBytes) + (size_t)n * 3 * iplane;
+    float *gflt = gin + (size_t)n * 3 * iplane;
+
+    int rowy[ROWS];
+    bool rowon[ROWS];  // wave-uniform: rows past the bottom edge add nothing
+    size_t roff[ROWS];
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+        const int yr = ty0 + wy + WAVES * j;
+        rowon[j] = yr < g.H;
+        rowy[j] = min(yr, g.H - 1);
+        roff[j] = (size_t)rowy[j] * g.W;
+    }
+
+    TapCol<ROWS> cur;
+    load_tap_col<ROWS>(cur, wb, ab, bb, plane, 0, roff, (unsigned)x);
+    for (int i = tid; i < 3 * CS; i += 64 * WAVES) acc[i] = 0;
+    __syncthreads();
+
+    float d[ROWS][3];
+    float mabs[ROWS];
+    int rowbase[ROWS];
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+        const float on = (lane_on && rowon[j]) ? scale : 0.f;  // masks edge duplicates
+        d[j][0] = ld_stream(gb_ + roff[j] + (unsigned)x) * on;
+        d[j][1] = ld_stream(gb_ + plane + roff[j] + (unsigned)x) * on;
+        d[j][2] = ld_stream(gb_ + 2 * plane + roff[j] + (unsigned)x) * on;
+        mabs[j] = 0.f;
+        rowbase[j] = (rowy[j] - ty0 + R) * LW + px + R;
+    }
+    static_for<0, 25>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        constexpr int r = t / 5, s = t % 5;
+        TapCol<ROWS> nxt;
+        if (t < 24) load_tap_col<ROWS>(nxt, wb, ab, bb, plane, t + 1, roff, (unsigned)x);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {
+            const float wv = cur.w[j], a = cur.a[j], b = cur.b[j];
+            const int ia = (int)a, ib = (int)b;
+            const float fa = a - (float)ia, fb = b - (float)ib;
+            mabs[j] = track_abs(mabs[j], a, b);
+            if (fmaxf(fabsf(a), fabsf(b)) < (float)(R + 1)) {  // footprint inside the tile
+                acc_t *p = acc + (__mul24(ia, LW) + ib + rowbase[j] + (r * LW + s));
+                const float ga = 1.f - fa, gb = 1.f - fb;
+                const float c00 = ga * gb, c10 = fa * gb, c01 = ga * fb, c11 = fa * fb;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float dw = d[j][c] * wv;
+                    atomicAdd(p + c * CS, to_fixed(dw * c00));  // ds_add_u64
+                    atomicAdd(p + c * CS + LW, to_fixed(dw * c10));
+                    atomicAdd(p + c * CS + 1, to_fixed(dw * c01));
+                    atomicAdd(p + c * CS + LW + 1, to_fixed(dw * c11));
+                }
+            }
+            asm volatile("" : "+v"(mabs[j]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+    });
+    __syncthreads();
+
+    // flush the tile: texel (ly, lx) is frame pixel (clamp(gy0 + ly), clamp(gx0 + lx))
+    const int gy0 = ty0 + g.oy0 - R, gx0 = tx0 + g.ox0 - R;
+    for (int i = tid; i < CS; i += 64 * WAVES) {
+        const int ly = i / LW, lx = i - ly * LW;
+        const int gy = clampi(gy0 + ly, 0, g.Hin - 1), gx = clampi(gx0 + lx, 0, g.Win - 1);
+        const size_t o = (size_t)gy * g.Win + gx;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const acc_t v = acc[c * CS + i];
+            if (v != 0) {
+                if constexpr (FIXED)
+                    atomicAdd(gfix + c * iplane + o, v);
+                else
+                    atomicAdd(gflt + c * iplane + o, (float)ldexp((double)(long long)v, -slog2));
+            }
+        }
+    }
+
+    // taps that left the tile: straight to memory, lane by lane (rare)
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+        if (!(mabs[j] < (float)(R + 1)) && lane_on && rowon[j]) {
+            const int y = rowy[j];
+            const size_t pix = roff[j] + x;
+#pragma unroll 1
+            for (int t = 0; t < 25; ++t) {
+                const size_t o = (size_t)t * plane + pix;
+                const float a = ab[o], b = bb[o];
+                if (fmaxf(fabsf(a), fabsf(b)) < (float)(R + 1)) continue;
+                const float wv = wb[o];
+                const int r = t / 5, s2 = t - 5 * r;
+                const TapIdx ti = tap_index(g, a, b, y + g.oy0 + r, x + g.ox0 + s2);
+                const float ga = 1.f - ti.fa, gb = 1.f - ti.fb;
+                const float c00 = ga * gb, c10 = ti.fa * gb, c01 = ga * ti.fb, c11 = ti.fa * ti.fb;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float dw = d[j][c] * wv;  // d carries the fixed-point scale
+                    if constexpr (FIXED) {
+                        acc_t *p = gfix + c * iplane;
+                        atomicAdd(p + ti.bl, to_fixed(dw * c00));
+                        atomicAdd(p + ti.tl, to_fixed(dw * c10));
+                        atomicAdd(p + ti.br, to_fixed(dw * c01));
+                        atomicAdd(p + ti.tr, to_fixed(dw * c11));
+                    } else {
+                        float *p = gflt + c * iplane;
+                        const float un = dw * ldexpf(1.f, -slog2);
+                        atomicAdd(p + ti.bl, un * c00);
+                        atomicAdd(p + ti.tl, un * c10);
+                        atomicAdd(p + ti.br, un * c01);
+                        atomicAdd(p + ti.tr, un * c11);
+                    }
+                }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void offset_radius_kernel(const float *__restrict__ oy,
                                                              const float *__restrict__ ox,
                                                              size_t count, int *__restrict__ out)
@@ -1174,6 +1359,25 @@ void launch_fwd_direct(int ch, dim3 grid, dim3 block, hipStream_t st, const floa
     }
 }
 
+// gradInput tiles: 64 x 16 pixels, 64-bit accumulators (3 x 29 x 77 x 8 B = 53.6 KB at R = 4)
+template <int R, bool FIXED>
+void launch_gin_tiled(const float *w, const float *oy, const float *ox, const float *gout, float *gin,
+                      unsigned char *ws, const Geom &g, int bits, hipStream_t st)
+{
+    constexpr int ROWS = 4;
+    hipLaunchKernelGGL((synth_gin_tiled<R, 4, ROWS, FIXED>), pixel_grid(g, 4 * ROWS), dim3(64, 4), 0, st,
+                       w, oy, ox, gout, gin, ws, g, bits);
+}
+
+// Workspace: deterministic mode = header + int64 image; fp32-atomic mode = header only, and only
+// when the LDS-staged kernel (which scales to fixed point on chip) will run.
+size_t ws_bytes_needed(const Geom &g, int gin_mode, int R)
+{
+    if (gin_mode == ARTEMIS_SYNTH_GIN_DETERMINISTIC)
+        return kDetHeaderBytes + (size_t)g.N * g.C * g.Hin * g.Win * sizeof(long long);
+    return R > 0 ? kDetHeaderBytes : 0;
+}
+
 int count_bits_for(const Geom &g)
 {
     // contributions that can land on one gradInput element: every tap corner of its plane
@@ -1230,10 +1434,10 @@ int artemis_synth_forward(const float *input, const float *weight, const float *
 size_t artemis_synth_backward_workspace_bytes(int N, int C, int H, int W, int k, int d,
                                               int gin_mode)
 {
-    if (gin_mode != ARTEMIS_SYNTH_GIN_DETERMINISTIC) return 0;
     Geom g;
     if (make_geom(g, N, C, H, W, k, d) != 0) return 0;
-    return kDetHeaderBytes + (size_t)N * C * g.Hin * g.Win * sizeof(long long);
+    // radius-independent upper bound: any tile_radius may be passed to the backward call
+    return ws_bytes_needed(g, gin_mode, tiled_ok(g) ? 1 : 0);
 }
 
 int artemis_synth_backward(const float *input, const float *weight, const float *offset_y,
@@ -1281,33 +1485,56 @@ int artemis_synth_backward(const float *input, const float *weight, const float 
     }
 
     if (grad_input) {
-        if (gin_mode == ARTEMIS_SYNTH_GIN_ATOMIC) {
-            hipError_t e = hipMemsetAsync(grad_input, 0, gin_count * sizeof(float), st);
-            if (e != hipSuccess) return fail((int)e, "hipMemsetAsync: %s", hipGetErrorString(e));
-            hipLaunchKernelGGL(synth_gin_atomic_direct, pixel_grid(g, 4), dim3(64, 4), 0, st, weight,
-                               offset_y, offset_x, grad_output, grad_input, g);
-        } else {
-            const size_t need = kDetHeaderBytes + gin_count * sizeof(long long);
-            if (!workspace || workspace_bytes < need)
-                return fail(hipErrorInvalidValue,
-                            "artemis_synth_backward: deterministic grad_input needs %zu workspace "
-                            "bytes, got %zu", need, workspace ? workspace_bytes : (size_t)0);
-            if (((uintptr_t)workspace & 15) != 0)
-                return fail(hipErrorInvalidValue, "artemis_synth_backward: workspace not 16-byte aligned");
-            unsigned char *ws = (unsigned char *)workspace;
-            hipError_t e = hipMemsetAsync(ws, 0, need, st);
-            if (e != hipSuccess) return fail((int)e, "hipMemsetAsync: %s", hipGetErrorString(e));
+        const int Rg = tiled_ok(g) ? pick_radius(tile_radius) : 0;
+        const int bits = count_bits_for(g);
+        const bool fixed = gin_mode == ARTEMIS_SYNTH_GIN_DETERMINISTIC;
+        const size_t need = ws_bytes_needed(g, gin_mode, Rg);
+        if (need && (!workspace || workspace_bytes < need))
+            return fail(hipErrorInvalidValue,
+                        "artemis_synth_backward: grad_input needs %zu workspace bytes "
+                        "(artemis_synth_backward_workspace_bytes), got %zu", need,
+                        workspace ? workspace_bytes : (size_t)0);
+        if (need && ((uintptr_t)workspace & 15) != 0)
+            return fail(hipErrorInvalidValue, "artemis_synth_backward: workspace not 16-byte aligned");
+        unsigned char *ws = (unsigned char *)workspace;
+        hipError_t e = hipSuccess;
+        if (need) e = hipMemsetAsync(ws, 0, need, st);
+        if (e == hipSuccess && !fixed) e = hipMemsetAsync(grad_input, 0, gin_count * sizeof(float), st);
+        if (e != hipSuccess) return fail((int)e, "hipMemsetAsync: %s", hipGetErrorString(e));
+        if (need) {  // maxima for the fixed-point scale
             const size_t wcount = (size_t)N * k * k * H * W, gcount = (size_t)N * C * H * W;
             hipLaunchKernelGGL(absmax_kernel, dim3(reduce_blocks(wcount)), dim3(256), 0, st, weight,
                                wcount, (unsigned *)ws);
             hipLaunchKernelGGL(absmax_kernel, dim3(reduce_blocks(gcount)), dim3(256), 0, st,
                                grad_output, gcount, (unsigned *)ws + 1);
-            const int bits = count_bits_for(g);
-            hipLaunchKernelGGL(synth_gin_fixed_direct, pixel_grid(g, 4), dim3(64, 4), 0, st, weight,
-                               offset_y, offset_x, grad_output, ws, g, bits);
+        }
+        if (Rg > 0) {
+            switch (Rg * 2 + (fixed ? 1 : 0)) {
+            case 4: launch_gin_tiled<2, false>(weight, offset_y, offset_x, grad_output, grad_input, ws, g, bits, st); break;
+            case 5: launch_gin_tiled<2, true>(weight, offset_y, offset_x, grad_output, grad_input, ws, g, bits, st); break;
+            case 8: launch_gin_tiled<4, false>(weight, offset_y, offset_x, grad_output, grad_input, ws, g, bits, st); break;
+            case 9: launch_gin_tiled<4, true>(weight, offset_y, offset_x, grad_output, grad_input, ws, g, bits, st); break;
+            case 16: launch_gin_tiled<8, false>(weight, offset_y, offset_x, grad_output, grad_input, ws, g, bits, st); break;
+            default: launch_gin_tiled<8, true>(weight, offset_y, offset_x, grad_output, grad_input, ws, g, bits, st); break;
+            }
+        } else if (!fixed) {
+            if (k == 5 && C == 3)
+                hipLaunchKernelGGL((synth_gin_atomic_direct<3, 5>), pixel_grid(g, 4), dim3(64, 4), 0, st,
+                                   weight, offset_y, offset_x, grad_output, grad_input, g);
+            else
+                hipLaunchKernelGGL((synth_gin_atomic_direct<0, 0>), pixel_grid(g, 4), dim3(64, 4), 0, st,
+                                   weight, offset_y, offset_x, grad_output, grad_input, g);
+        } else {
+            if (k == 5 && C == 3)
+                hipLaunchKernelGGL((synth_gin_fixed_direct<3, 5>), pixel_grid(g, 4), dim3(64, 4), 0, st,
+                                   weight, offset_y, offset_x, grad_output, ws, g, bits);
+            else
+                hipLaunchKernelGGL((synth_gin_fixed_direct<0, 0>), pixel_grid(g, 4), dim3(64, 4), 0, st,
+                                   weight, offset_y, offset_x, grad_output, ws, g, bits);
+        }
+        if (fixed)
             hipLaunchKernelGGL(det_finalize_kernel, dim3(reduce_blocks(gin_count)), dim3(256), 0, st,
                                ws, grad_input, gin_count, bits);
-        }
         const int e2 = check_launch("artemis_synth_backward (grad_input)");
         if (e2) return e2;
     }

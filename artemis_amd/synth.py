@@ -145,10 +145,11 @@ class FunctionSynth(torch.autograd.Function):
             deterministic = options.deterministic or torch.are_deterministic_algorithms_enabled()
             mode = _lib.GIN_DETERMINISTIC if deterministic else _lib.GIN_ATOMIC
             workspace, ws_bytes = None, 0
-            if need[0] and deterministic:
+            if need[0]:
                 ws_bytes = lib.artemis_synth_backward_workspace_bytes(
                     N, C, H, W, k, int(dilation), mode)
-                workspace = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=input.device)
+                if ws_bytes:
+                    workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=input.device)
             stream = torch.cuda.current_stream().cuda_stream
             if any(need[:4]):
                 _lib.check(lib.artemis_synth_backward(

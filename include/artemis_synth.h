@@ -52,8 +52,8 @@ extern "C" {
 #define ARTEMIS_SYNTH_RADIUS_NONE 0
 
 /* grad_input accumulation mode of artemis_synth_backward */
-#define ARTEMIS_SYNTH_GIN_ATOMIC 0        /* fp32 atomics; run-to-run last-bit differences */
-#define ARTEMIS_SYNTH_GIN_DETERMINISTIC 1 /* bit-exact run to run; needs the workspace */
+#define ARTEMIS_SYNTH_GIN_ATOMIC 0        /* fp32 atomics across tiles; last-bit run-to-run noise */
+#define ARTEMIS_SYNTH_GIN_DETERMINISTIC 1 /* bit-exact run to run; needs the large workspace */
 
 /* Replaces the kernel_Synth_updateOutput launch, cupy_module/synth.py:297-309
  * (kernel text :6-52; called from FunctionSynth.forward :265-313).
@@ -71,9 +71,11 @@ int artemis_synth_forward(const float *input, const float *weight, const float *
  *
  * grad_input has no counterpart in the reference, which returns unfilled zeros (:333, :391);
  * here it is the true adjoint of the forward w.r.t. `input`.  gin_mode selects fp32 atomics or
- * the deterministic accumulation; the latter needs `workspace` of at least
- * artemis_synth_backward_workspace_bytes(...) bytes (device memory, 16-byte aligned, contents
- * undefined on entry and exit).  `workspace` may be NULL otherwise.
+ * the deterministic (integer fixed-point) accumulation.  When grad_input is requested,
+ * `workspace` must hold at least artemis_synth_backward_workspace_bytes(...) bytes for that
+ * gin_mode (device memory, 16-byte aligned, contents undefined on entry and exit): 256 bytes in
+ * atomic mode, 256 + 8 bytes per grad_input element in deterministic mode.  `workspace` may be
+ * NULL when grad_input is NULL or the size query returns 0.
  * Channels: the reference hard-codes 3 (:75, :125, :175); any C >= 1 is summed here. */
 int artemis_synth_backward(const float *input, const float *weight, const float *offset_y,
                            const float *offset_x, const float *grad_output, float *grad_input,
@@ -82,8 +84,8 @@ int artemis_synth_backward(const float *input, const float *weight, const float 
                            void *workspace, size_t workspace_bytes, void *stream);
 
 /* Bytes of workspace artemis_synth_backward needs for these dimensions and gin_mode when
- * grad_input is requested (0 when none is needed).  Host-only arithmetic; no reference
- * counterpart (the reference has no grad_input kernel). */
+ * grad_input is requested, valid for every tile_radius (0 when none is needed).  Host-only
+ * arithmetic; no reference counterpart (the reference has no grad_input kernel). */
 size_t artemis_synth_backward_workspace_bytes(int N, int C, int H, int W, int k, int d,
                                               int gin_mode);
 

@@ -59,7 +59,9 @@ def test_header_constants_match_binding():
 def test_workspace_bytes():
     lib = _lib.load()
     f = lib.artemis_synth_backward_workspace_bytes
-    assert f(2, 3, 6, 7, 5, 1, _lib.GIN_ATOMIC) == 0
+    # atomic mode: just the 256-byte header (fixed-point scale), and only for the LDS-staged shape
+    assert f(2, 3, 6, 7, 5, 1, _lib.GIN_ATOMIC) == 256
+    assert f(1, 2, 5, 9, 3, 2, _lib.GIN_ATOMIC) == 0
     # header (256 B) + one int64 per gradInput element
     assert f(2, 3, 6, 7, 5, 1, _lib.GIN_DETERMINISTIC) == 256 + 2 * 3 * 10 * 11 * 8
     assert f(1, 3, 1080, 1920, 5, 1, _lib.GIN_DETERMINISTIC) == 256 + 3 * 1084 * 1924 * 8

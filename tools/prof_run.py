@@ -33,9 +33,8 @@ def main():
     wsb = 0
     if a.gin >= 0:
         gin = torch.empty_like(frames[0]["inp"])
-        if a.gin == 1:
-            wsb = lib.artemis_synth_backward_workspace_bytes(1, 3, H, W, 5, 1, 1)
-            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        wsb = lib.artemis_synth_backward_workspace_bytes(1, 3, H, W, 5, 1, a.gin)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     for _ in range(a.iters):
         for f in frames:
             _lib.check(lib.artemis_synth_forward(

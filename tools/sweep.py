@@ -80,7 +80,7 @@ def main():
                 variants[nm] = (lambda mode=mode: _lib.check(lib.artemis_synth_backward(
                     inp.data_ptr(), w.data_ptr(), oy.data_ptr(), ox.data_ptr(), gout.data_ptr(),
                     gin.data_ptr(), None, None, None, N, 3, H, W, 5, 1, mode, -1,
-                    ws.data_ptr() if mode else None, ws_bytes if mode else 0, st), "gin"),
+                    ws.data_ptr(), ws_bytes, st), "gin"),
                     12.0 * px)
         times = {k: [] for k in variants}
         for k, (fn, _) in variants.items():
