@@ -335,7 +335,8 @@ __global__ __launch_bounds__(256) void det_finalize_kernel(const unsigned char *
 
 // ------------------------------------------------------------------------------------------
 // LDS-staged kernels for k = 5, d = 1, C = 3 (the model's configuration).
-// Workgroup = 256 lanes as (64, 4): tile of 64 x TH output pixels; wave w owns rows w, w+4, ...
+// Workgroup = WAVES waves as (64, WAVES): tile of 64 x TH output pixels, TH = WAVES * ROWS; wave w
+// owns rows w, w + WAVES, ...
 // LDS tile: (TH + 5 + 2R) x (64 + 5 + 2R) float4 texels, texel (ly, lx) = the three channels of
 // frame pixel (clamp(gy0 + ly), clamp(gx0 + lx)): the reference's CLAMP is applied at fill
 // time, so reading (ly, ly+1) x (lx, lx+1) needs no clamp.  A tap is served from LDS when
@@ -372,20 +373,6 @@ struct TileShape {
     static constexpr int LH = TH + 5 + 2 * R;
 };
 
-template <int R, int TH>
-__device__ __forceinline__ void fill_tile(f32x4 *tile, const float *__restrict__ ip, const Geom &g,
-                                          int gy0, int gx0, int tid)
-{
-    constexpr int LW = TileShape<R, TH>::LW, LH = TileShape<R, TH>::LH;
-    const int iplane = g.Hin * g.Win;
-    for (int i = tid; i < LH * LW; i += 256) {
-        const int ly = i / LW, lx = i - ly * LW;
-        const int gy = clampi(gy0 + ly, 0, g.Hin - 1), gx = clampi(gx0 + lx, 0, g.Win - 1);
-        const int o = gy * g.Win + gx;
-        tile[i] = f32x4{ip[o], ip[(size_t)iplane + o], ip[2 * (size_t)iplane + o], 0.f};
-    }
-}
-
 // The 75 weight/offset planes and the gradient planes are touched exactly once per launch:
 // non-temporal accesses keep them from displacing the (re-read) frame in L2 and, measured on
 // MI355X, lift a mixed read/write stream from ~4.9 to ~6.3 TB/s (tools/exp/exp_bw.hip).
@@ -409,250 +396,15 @@ __device__ __forceinline__ void st_stream(float *p, float v)
 #endif
 }
 
-// One tap row (5 taps) of the three streamed planes for one pixel, held in registers.
-struct TapRow {
-    float w[5], a[5], b[5];
-};
-
-// wrow/arow/brow: wave-uniform pointers to (tap 0, row y, x = 0); x: this lane's column.
-// Uniform base + 32-bit lane offset keeps the address math on the scalar unit
-// (global_load_dword v, v_off, s[base]).
-__device__ __forceinline__ void load_tap_row(TapRow &t, const float *__restrict__ wrow,
-                                             const float *__restrict__ arow,
-                                             const float *__restrict__ brow, size_t plane, int r,
-                                             unsigned x)
-{
-#pragma unroll
-    for (int s = 0; s < 5; ++s) {
-        const size_t o = (size_t)(r * 5 + s) * plane;
-        t.w[s] = ld_stream(wrow + o + x);
-        t.a[s] = ld_stream(arow + o + x);
-        t.b[s] = ld_stream(brow + o + x);
-    }
-}
-
-struct Corners {
-    f32x4 bl, tl, br, tr;
-};
-
-// The 2x2 x 3-channel footprint of one tap from the staged tile.  The hot loop is branch-free:
-// a footprint outside the tile reads an in-bounds (meaningless) texel and raises `bad`; a lane
-// with `bad` set recomputes its pixel through the direct path after the loop.
-template <int R, int TH>
-__device__ __forceinline__ Corners tile_corners(const lds_f32x4 *tile, int ly, int lx, bool &bad)
-{
-    constexpr int LW = TileShape<R, TH>::LW, LH = TileShape<R, TH>::LH;
-    bad |= (unsigned)ly >= (unsigned)(LH - 1);
-    bad |= (unsigned)lx >= (unsigned)(LW - 1);
-    // 24-bit multiply: exact whenever the footprint is inside; anything else is clamped in-bounds
-    const unsigned idx = min(__umul24((unsigned)ly, (unsigned)LW) + (unsigned)lx,
-                             (unsigned)((LH - 1) * LW - 2));
-    const lds_f32x4 *p = tile + idx;
-    Corners q;
-    q.bl = p[0];
-    q.br = p[1];
-    q.tl = p[LW];
-    q.tr = p[LW + 1];
-    return q;
-}
-
-// Same gather, with the out-of-tile test deferred: the caller keeps the running unsigned maxima
-// of ly and lx (a negative index is a huge unsigned) and tests them once per pixel.  Two v_max
-// per tap, and -- unlike a bool that is OR-ed up -- nothing the optimiser can postpone while
-// keeping every ly/lx of the pixel alive.
-template <int R, int TH>
-__device__ __forceinline__ Corners tile_corners_max(const lds_f32x4 *tile, int ly, int lx,
-                                                    unsigned &mly, unsigned &mlx)
-{
-    constexpr int LW = TileShape<R, TH>::LW, LH = TileShape<R, TH>::LH;
-    mly = max(mly, (unsigned)ly);
-    mlx = max(mlx, (unsigned)lx);
-    const unsigned idx = min(__umul24((unsigned)ly, (unsigned)LW) + (unsigned)lx,
-                             (unsigned)((LH - 1) * LW - 2));
-    const lds_f32x4 *p = tile + idx;
-    Corners q;
-    q.bl = p[0];
-    q.br = p[1];
-    q.tl = p[LW];
-    q.tr = p[LW + 1];
-    return q;
-}
-
-template <int R, int TH>
-__device__ __forceinline__ bool tile_missed(unsigned mly, unsigned mlx)
-{
-    return mly >= (unsigned)(TileShape<R, TH>::LH - 1) || mlx >= (unsigned)(TileShape<R, TH>::LW - 1);
-}
-
-template <int R, int TH>
-__global__ __launch_bounds__(256, 4) void synth_fwd_tiled(const float *__restrict__ in,
-                                                           const float *__restrict__ w,
-                                                           const float *__restrict__ oy,
-                                                           const float *__restrict__ ox,
-                                                           float *__restrict__ out, Geom g)
-{
-    constexpr int LW = TileShape<R, TH>::LW, LH = TileShape<R, TH>::LH;
-    __shared__ f32x4 tile[LH * LW];
-    const lds_f32x4 *ltile = (const lds_f32x4 *)tile;
-    const int tx0 = blockIdx.x * kTW, ty0 = blockIdx.y * TH, n = blockIdx.z;
-    const int wy = __builtin_amdgcn_readfirstlane(threadIdx.y);  // wave index: uniform
-    const int tid = wy * 64 + threadIdx.x;
-    const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
-    const float *ip = in + (size_t)n * 3 * iplane;
-    const int px = threadIdx.x, x = tx0 + px;
-    const bool active = x < g.W && ty0 + wy < g.H;
-    const size_t nbase = (size_t)n * 25 * plane;
-
-    // first tap row of this lane's first pixel: issued before the tile fill so the stream is
-    // already in flight while the tile is staged
-    TapRow cur;
-    size_t rowoff = nbase + (size_t)(ty0 + wy) * g.W;  // uniform
-    if (active) load_tap_row(cur, w + rowoff, oy + rowoff, ox + rowoff, plane, 0, (unsigned)x);
-
-    fill_tile<R, TH>(tile, ip, g, ty0 + g.oy0 - R, tx0 + g.ox0 - R, tid);
-    __syncthreads();
-    if (!active) return;
-
-#pragma unroll 1
-    for (int py = wy; py < TH; py += 4) {
-        const int y = ty0 + py;
-        const bool more = py + 4 < TH && y + 4 < g.H;  // wave-uniform
-        const float *wrow = w + rowoff, *arow = oy + rowoff, *brow = ox + rowoff;
-        float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
-        bool bad = false;
-#pragma unroll
-        for (int r = 0; r < 5; ++r) {
-            TapRow nxt;
-            if (r < 4) {
-                load_tap_row(nxt, wrow, arow, brow, plane, r + 1, (unsigned)x);
-            } else if (more) {
-                const size_t o = (size_t)4 * g.W;
-                load_tap_row(nxt, wrow + o, arow + o, brow + o, plane, 0, (unsigned)x);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int s = 0; s < 5; ++s) {
-                const float wv = cur.w[s], a = cur.a[s], b = cur.b[s];
-                const int ia = (int)a, ib = (int)b;
-                const float fa = a - (float)ia, fb = b - (float)ib;
-                const Corners q =
-                    tile_corners<R, TH>(ltile, wadd(py + r + R, ia), wadd(px + s + R, ib), bad);
-                const float ga = 1.f - fa, gb = 1.f - fb;
-                const float c00 = ga * gb, c10 = fa * gb, c01 = ga * fb, c11 = fa * fb;
-                acc0 += wv * (q.bl.x * c00 + q.tl.x * c10 + q.br.x * c01 + q.tr.x * c11);
-                acc1 += wv * (q.bl.y * c00 + q.tl.y * c10 + q.br.y * c01 + q.tr.y * c11);
-                acc2 += wv * (q.bl.z * c00 + q.tl.z * c10 + q.br.z * c01 + q.tr.z * c11);
-            }
-            // Pin this row's arithmetic before the barrier: instruction selection otherwise
-            // floats the (chain-free) FMAs to the end of the unrolled block and keeps every
-            // LDS result of the pixel live.
-            asm volatile("" : "+v"(acc0), "+v"(acc1), "+v"(acc2));
-            __builtin_amdgcn_sched_barrier(0);
-            cur = nxt;
-        }
-        // Stored unconditionally (a conditional store lets the optimiser sink the whole
-        // accumulation past the loop); a lane with an out-of-tile tap then overwrites it.
-        float *orow = out + (size_t)n * 3 * plane + (size_t)y * g.W;
-        st_stream(orow + (unsigned)x, acc0);
-        st_stream(orow + plane + (unsigned)x, acc1);
-        st_stream(orow + 2 * plane + (unsigned)x, acc2);
-        if (bad) fwd_pixel_direct<3, 5>(ip, wrow + x, arow + x, brow + x, orow + x, g, y, x);
-        if (!more) break;
-        rowoff += (size_t)4 * g.W;
-    }
-}
-
-// ALL: the three gradients are all requested (the model's case); the run-time null checks of
-// the general variant would otherwise put 75 scalar branches in the unrolled body.
-template <int R, int TH, bool ALL>
-__global__ __launch_bounds__(256, 4) void synth_bwd_tiled(const float *__restrict__ in,
-                                                           const float *__restrict__ w,
-                                                           const float *__restrict__ oy,
-                                                           const float *__restrict__ ox,
-                                                           const float *__restrict__ gout,
-                                                           float *__restrict__ gw,
-                                                           float *__restrict__ goy,
-                                                           float *__restrict__ gox, Geom g)
-{
-    constexpr int LW = TileShape<R, TH>::LW, LH = TileShape<R, TH>::LH;
-    __shared__ f32x4 tile[LH * LW];
-    const lds_f32x4 *ltile = (const lds_f32x4 *)tile;
-    const int tx0 = blockIdx.x * kTW, ty0 = blockIdx.y * TH, n = blockIdx.z;
-    const int wy = __builtin_amdgcn_readfirstlane(threadIdx.y);  // wave index: uniform
-    const int tid = wy * 64 + threadIdx.x;
-    const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
-    const float *ip = in + (size_t)n * 3 * iplane;
-    const int px = threadIdx.x, x = tx0 + px;
-    const bool active = x < g.W && ty0 + wy < g.H;
-    const size_t nbase = (size_t)n * 25 * plane;
-
-    TapRow cur;
-    size_t rowoff = nbase + (size_t)(ty0 + wy) * g.W;  // uniform
-    if (active) load_tap_row(cur, w + rowoff, oy + rowoff, ox + rowoff, plane, 0, (unsigned)x);
-
-    fill_tile<R, TH>(tile, ip, g, ty0 + g.oy0 - R, tx0 + g.ox0 - R, tid);
-    __syncthreads();
-    if (!active) return;
-
-#pragma unroll 1
-    for (int py = wy; py < TH; py += 4) {
-        const int y = ty0 + py;
-        const bool more = py + 4 < TH && y + 4 < g.H;  // wave-uniform
-        const float *wrow = w + rowoff, *arow = oy + rowoff, *brow = ox + rowoff;
-        const float *grow = gout + (size_t)n * 3 * plane + (size_t)y * g.W;
-        const float d0 = ld_stream(grow + (unsigned)x), d1 = ld_stream(grow + plane + (unsigned)x),
-                    d2 = ld_stream(grow + 2 * plane + (unsigned)x);
-        bool bad = false;
-#pragma unroll
-        for (int r = 0; r < 5; ++r) {
-            TapRow nxt;
-            if (r < 4) {
-                load_tap_row(nxt, wrow, arow, brow, plane, r + 1, (unsigned)x);
-            } else if (more) {
-                const size_t o = (size_t)4 * g.W;
-                load_tap_row(nxt, wrow + o, arow + o, brow + o, plane, 0, (unsigned)x);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int s = 0; s < 5; ++s) {
-                const float wv = cur.w[s], a = cur.a[s], b = cur.b[s];
-                const int ia = (int)a, ib = (int)b;
-                const float fa = a - (float)ia, fb = b - (float)ib;
-                const Corners q =
-                    tile_corners<R, TH>(ltile, wadd(py + r + R, ia), wadd(px + s + R, ib), bad);
-                const float pbl = d0 * q.bl.x + d1 * q.bl.y + d2 * q.bl.z;
-                const float ptl = d0 * q.tl.x + d1 * q.tl.y + d2 * q.tl.z;
-                const float pbr = d0 * q.br.x + d1 * q.br.y + d2 * q.br.z;
-                const float ptr_ = d0 * q.tr.x + d1 * q.tr.y + d2 * q.tr.z;
-                const float ga = 1.f - fa, gb = 1.f - fb;
-                const size_t t = rowoff + (size_t)(r * 5 + s) * plane;  // uniform
-                if (ALL || gw)
-                    st_stream(gw + t + (unsigned)x, pbl * (ga * gb) + ptl * (fa * gb) +
-                                                        pbr * (ga * fb) + ptr_ * (fa * fb));
-                if (ALL || goy)
-                    st_stream(goy + t + (unsigned)x, wv * ((ptl - pbl) * gb + (ptr_ - pbr) * fb));
-                if (ALL || gox)
-                    st_stream(gox + t + (unsigned)x, wv * ((pbr - pbl) * ga + (ptr_ - ptl) * fa));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            cur = nxt;
-        }
-        if (bad)
-            bwd_pixel_direct<3, 5>(ip, wrow + x, arow + x, brow + x, grow + x,
-                             gw ? gw + rowoff + x : nullptr, goy ? goy + rowoff + x : nullptr,
-                             gox ? gox + rowoff + x : nullptr, g, y, x);
-        if (!more) break;
-        rowoff += (size_t)4 * g.W;
-    }
-}
-
 // ------------------------------------------------------------------------------------------
-// Cooperative fix-up (k = 5, d = 1, C = 3).  A pixel whose taps may leave the staged tile is
-// recomputed through clamped global gathers.  Such pixels are rare (a few dozen per 1080p frame
-// at sigma = 1) but a lane that walks its 25 taps alone pays ~50 dependent memory round trips at
-// the very end of its workgroup, and the launch cannot end before the slowest workgroup: measured,
-// that tail cost 8 us (forward) to 50 us (backward) per launch.  Here the whole wave recomputes
-// one flagged pixel at a time, lane l < 25 owning tap l: two round trips per pixel.
+// Fix-up of taps that leave the staged tile (k = 5, d = 1, C = 3).  The hot loops give such a
+// tap weight 0 (forward) or let its stores be overwritten (backward); afterwards only those taps
+// are recomputed through clamped global gathers, so the cost grows with the number of far taps,
+// not with 25 x the number of pixels that have one.  When few pixels of a wave are affected
+// (a few dozen per 1080p frame at sigma = 1) the whole wave handles one pixel at a time, lane
+// l < 25 owning tap l: two memory round trips per pixel.  A lane walking its taps alone pays
+// up to 50 dependent round trips at the very end of its workgroup, and a launch cannot end before
+// its slowest workgroup: measured, that tail cost 8 us (forward) to 50 us (backward) per launch.
 // All 64 lanes must be active (the tap-major kernels never retire single lanes).
 // ------------------------------------------------------------------------------------------
 
@@ -665,55 +417,97 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
-// wb/ab/bb: tap 0 of the sample's planes; ip: the sample's frame; on: the sample's output planes
-__device__ __forceinline__ void fwd_pixel_coop(const float *__restrict__ ip, const float *__restrict__ wb,
-                                            const float *__restrict__ ab,
-                                            const float *__restrict__ bb, float *__restrict__ on,
-                                            const Geom &g, int y, int xs)
+struct Float3 {
+    float x, y, z;
+};
+
+// A tap is served from the staged tile iff both of its offsets satisfy |offset| < R + 1.  The
+// hot loops and the fix-ups below use this one predicate, so every tap is computed exactly once.
+template <int R>
+__device__ __forceinline__ bool tap_in_tile(float a, float b)
 {
-    const int l = threadIdx.x & 63;
-    const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
-    const size_t pix = (size_t)y * g.W + xs;
-    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-    if (l < 25) {
-        const size_t o = (size_t)l * plane + pix;
-        const float wv = wb[o], a = ab[o], b = bb[o];
-        const int r = l / 5, s = l - 5 * r;
-        const TapIdx ti = tap_index(g, a, b, y + g.oy0 + r, xs + g.ox0 + s);
-        const float ga = 1.f - ti.fa, gb = 1.f - ti.fb;
-        const float c00 = ga * gb, c10 = ti.fa * gb, c01 = ga * ti.fb, c11 = ti.fa * ti.fb;
-        const float *p0 = ip, *p1 = ip + iplane, *p2 = ip + 2 * iplane;
-        c0 = wv * (p0[ti.bl] * c00 + p0[ti.tl] * c10 + p0[ti.br] * c01 + p0[ti.tr] * c11);
-        c1 = wv * (p1[ti.bl] * c00 + p1[ti.tl] * c10 + p1[ti.br] * c01 + p1[ti.tr] * c11);
-        c2 = wv * (p2[ti.bl] * c00 + p2[ti.tl] * c10 + p2[ti.br] * c01 + p2[ti.tr] * c11);
-    }
-    c0 = wave_sum(c0);
-    c1 = wave_sum(c1);
-    c2 = wave_sum(c2);
-    if (l == 0) {
-        on[pix] = c0;
-        on[plane + pix] = c1;
-        on[2 * plane + pix] = c2;
-    }
+    return fmaxf(fabsf(a), fabsf(b)) < (float)(R + 1);
 }
 
-// gn: the sample's gradOutput planes; gwn/goyn/goxn: tap 0 of the sample's gradient planes (or null)
-__device__ __forceinline__ void bwd_pixel_coop(const float *__restrict__ ip, const float *__restrict__ wb,
-                                            const float *__restrict__ ab,
-                                            const float *__restrict__ bb,
-                                            const float *__restrict__ gn, float *__restrict__ gwn,
-                                            float *__restrict__ goyn, float *__restrict__ goxn,
-                                            const Geom &g, int y, int xs)
+// Contribution of ONE tap (clamped global gathers), channels 0..2.
+__device__ __forceinline__ Float3 fwd_tap_global(const float *__restrict__ ip, const Geom &g, float wv,
+                                                 float a, float b, int yb, int xb)
+{
+    const size_t iplane = (size_t)g.Hin * g.Win;
+    const TapIdx ti = tap_index(g, a, b, yb, xb);
+    const float ga = 1.f - ti.fa, gb = 1.f - ti.fb;
+    const float c00 = ga * gb, c10 = ti.fa * gb, c01 = ga * ti.fb, c11 = ti.fa * ti.fb;
+    const float *p0 = ip, *p1 = ip + iplane, *p2 = ip + 2 * iplane;
+    Float3 o;
+    o.x = wv * (p0[ti.bl] * c00 + p0[ti.tl] * c10 + p0[ti.br] * c01 + p0[ti.tr] * c11);
+    o.y = wv * (p1[ti.bl] * c00 + p1[ti.tl] * c10 + p1[ti.br] * c01 + p1[ti.tr] * c11);
+    o.z = wv * (p2[ti.bl] * c00 + p2[ti.tl] * c10 + p2[ti.br] * c01 + p2[ti.tr] * c11);
+    return o;
+}
+
+// Sum over the out-of-tile taps of pixel (y, xs), computed by the whole wave (lane l < 25 owns
+// tap l).  wb/ab/bb: tap 0 of the sample's planes; ip: the sample's frame.  Result in every lane.
+template <int R>
+__device__ __forceinline__ Float3 fwd_outside_coop(const float *__restrict__ ip,
+                                                   const float *__restrict__ wb,
+                                                   const float *__restrict__ ab,
+                                                   const float *__restrict__ bb, const Geom &g, int y,
+                                                   int xs)
 {
     const int l = threadIdx.x & 63;
-    if (l >= 25) return;
-    const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
-    const size_t pix = (size_t)y * g.W + xs;
-    const size_t o = (size_t)l * plane + pix;
-    const float wv = wb[o], a = ab[o], b = bb[o];
-    const float d0 = gn[pix], d1 = gn[plane + pix], d2 = gn[2 * plane + pix];
-    const int r = l / 5, s = l - 5 * r;
-    const TapIdx ti = tap_index(g, a, b, y + g.oy0 + r, xs + g.ox0 + s);
+    const size_t plane = (size_t)g.H * g.W;
+    Float3 c = {0.f, 0.f, 0.f};
+    if (l < 25) {
+        const size_t o = (size_t)l * plane + (size_t)y * g.W + xs;
+        const float a = ab[o], b = bb[o];
+        if (!tap_in_tile<R>(a, b)) {
+            const int r = l / 5, s = l - 5 * r;
+            c = fwd_tap_global(ip, g, wb[o], a, b, y + g.oy0 + r, xs + g.ox0 + s);
+        }
+    }
+    c.x = wave_sum(c.x);
+    c.y = wave_sum(c.y);
+    c.z = wave_sum(c.z);
+    return c;
+}
+
+// The same sum by one lane for its own pixel (used when many lanes of the wave are flagged).
+template <int R>
+__device__ __forceinline__ Float3 fwd_outside_lane(const float *__restrict__ ip,
+                                                   const float *__restrict__ wp,
+                                                   const float *__restrict__ ap,
+                                                   const float *__restrict__ bp, const Geom &g, int y,
+                                                   int x)
+{
+    const size_t plane = (size_t)g.H * g.W;
+    Float3 c = {0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int r = 0; r < 5; ++r) {
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            const size_t o = (size_t)(r * 5 + s) * plane;
+            const float a = ap[o], b = bp[o];
+            if (!tap_in_tile<R>(a, b)) {
+                const Float3 t = fwd_tap_global(ip, g, wp[o], a, b, y + g.oy0 + r, x + g.ox0 + s);
+                c.x += t.x;
+                c.y += t.y;
+                c.z += t.z;
+            }
+        }
+    }
+    return c;
+}
+
+// One tap of the fused backward through clamped global gathers; o = element offset of
+// (tap, y, x) in the sample's 25-plane tensors.
+__device__ __forceinline__ void bwd_tap_global(const float *__restrict__ ip, const Geom &g, float wv,
+                                               float a, float b, float d0, float d1, float d2, int yb,
+                                               int xb, float *__restrict__ gwn,
+                                               float *__restrict__ goyn, float *__restrict__ goxn,
+                                               size_t o)
+{
+    const size_t iplane = (size_t)g.Hin * g.Win;
+    const TapIdx ti = tap_index(g, a, b, yb, xb);
     const float *p0 = ip, *p1 = ip + iplane, *p2 = ip + 2 * iplane;
     const float pbl = d0 * p0[ti.bl] + d1 * p1[ti.bl] + d2 * p2[ti.bl];
     const float ptl = d0 * p0[ti.tl] + d1 * p1[ti.tl] + d2 * p2[ti.tl];
@@ -724,6 +518,53 @@ __device__ __forceinline__ void bwd_pixel_coop(const float *__restrict__ ip, con
     if (gwn) gwn[o] = lft + ti.fb * across;
     if (goyn) goyn[o] = wv * (dlt + ti.fb * (drt - dlt));
     if (goxn) goxn[o] = wv * across;
+}
+
+// Out-of-tile taps of pixel (y, xs) recomputed and stored by the whole wave.
+// gn: the sample's gradOutput planes; gwn/goyn/goxn: tap 0 of the sample's gradient planes.
+template <int R>
+__device__ __forceinline__ void bwd_outside_coop(const float *__restrict__ ip,
+                                                 const float *__restrict__ wb,
+                                                 const float *__restrict__ ab,
+                                                 const float *__restrict__ bb,
+                                                 const float *__restrict__ gn, float *__restrict__ gwn,
+                                                 float *__restrict__ goyn, float *__restrict__ goxn,
+                                                 const Geom &g, int y, int xs)
+{
+    const int l = threadIdx.x & 63;
+    if (l >= 25) return;
+    const size_t plane = (size_t)g.H * g.W;
+    const size_t pix = (size_t)y * g.W + xs;
+    const size_t o = (size_t)l * plane + pix;
+    const float a = ab[o], b = bb[o];
+    if (tap_in_tile<R>(a, b)) return;
+    const int r = l / 5, s = l - 5 * r;
+    bwd_tap_global(ip, g, wb[o], a, b, gn[pix], gn[plane + pix], gn[2 * plane + pix], y + g.oy0 + r,
+                   xs + g.ox0 + s, gwn, goyn, goxn, o);
+}
+
+template <int R>
+__device__ __forceinline__ void bwd_outside_lane(const float *__restrict__ ip,
+                                                 const float *__restrict__ wb,
+                                                 const float *__restrict__ ab,
+                                                 const float *__restrict__ bb, float d0, float d1,
+                                                 float d2, float *__restrict__ gwn,
+                                                 float *__restrict__ goyn, float *__restrict__ goxn,
+                                                 const Geom &g, int y, int x)
+{
+    const size_t plane = (size_t)g.H * g.W;
+    const size_t pix = (size_t)y * g.W + x;
+#pragma unroll 1
+    for (int r = 0; r < 5; ++r) {
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            const size_t o = (size_t)(r * 5 + s) * plane + pix;
+            const float a = ab[o], b = bb[o];
+            if (!tap_in_tile<R>(a, b))
+                bwd_tap_global(ip, g, wb[o], a, b, d0, d1, d2, y + g.oy0 + r, x + g.ox0 + s, gwn, goyn,
+                               goxn, o);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -796,6 +637,10 @@ __device__ __forceinline__ void fill_tile_n(f32x4 *tile, const float *__restrict
         }
     }
 }
+
+struct Corners {
+    f32x4 bl, tl, br, tr;
+};
 
 // Byte address (within the tile) of the bottom-left texel of a tap's footprint:
 //   ((py + r + R + ia) * LW + (px + s + R + ib)) * 16
@@ -890,18 +735,22 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) {
-            const float wv = cur.w[j], a = cur.a[j], b = cur.b[j];
+            float wv = cur.w[j];
+            const float a = cur.a[j], b = cur.b[j];
             const int ia = (int)a, ib = (int)b;
             const float fa = a - (float)ia, fb = b - (float)ib;
             mabs[j] = track_abs(mabs[j], a, b);
             const Corners q = tile_corners_at<R, TH, r * LW + s>(ltile, ia, ib, rowbase[j]);
             const float ga = 1.f - fa, gb = 1.f - fb;
             const float c00 = ga * gb, c10 = fa * gb, c01 = ga * fb, c11 = fa * fb;
+            wv = tap_in_tile<R>(a, b) ? wv : 0.f;  // a far tap is added by the fix-up instead
             acc0[j] += wv * (q.bl.x * c00 + q.tl.x * c10 + q.br.x * c01 + q.tr.x * c11);
             acc1[j] += wv * (q.bl.y * c00 + q.tl.y * c10 + q.br.y * c01 + q.tr.y * c11);
             acc2[j] += wv * (q.bl.z * c00 + q.tl.z * c10 + q.br.z * c01 + q.tr.z * c11);
-            // pin the arithmetic in place (see synth_fwd_tiled) and bound the LDS results in
-            // flight to kRowGroup rows (16 VGPRs each)
+            // Pin the arithmetic in place: instruction selection otherwise floats the chain-free
+            // FMAs to the end of the unrolled block, keeping every LDS result of the pixel live
+            // (512 VGPRs or spills).  The sched_barrier bounds the LDS results in flight to
+            // kRowGroup rows (16 VGPRs each).
             asm volatile("" : "+v"(acc0[j]), "+v"(acc1[j]), "+v"(acc2[j]), "+v"(mabs[j]));
             if (j % kRowGroup == kRowGroup - 1) __builtin_amdgcn_sched_barrier(0);
         }
@@ -910,11 +759,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
     });
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) {
-        float *orow = out + (size_t)n * 3 * plane + roff[j];
-        st_stream(orow + (unsigned)x, acc0[j]);
-        st_stream(orow + plane + (unsigned)x, acc1[j]);
-        st_stream(orow + 2 * plane + (unsigned)x, acc2[j]);
-        // some tap may have left the tile: recompute the pixel through the direct path
+        // taps that left the tile are added through clamped global gathers
         const bool flag = !(mabs[j] < (float)(R + 1));
         unsigned long long todo = __ballot(flag && tx0 + (int)threadIdx.x == x);
         if (todo) {  // wave-uniform, rare
@@ -922,13 +767,25 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
                 while (todo) {
                     const int b = __ffsll((long long)todo) - 1;
                     todo &= todo - 1;
-                    fwd_pixel_coop(ip, wb, ab, bb, out + (size_t)n * 3 * plane, g, rowy[j], tx0 + b);
+                    const Float3 c = fwd_outside_coop<R>(ip, wb, ab, bb, g, rowy[j], tx0 + b);
+                    if (x == tx0 + b) {  // the owner and its right-edge duplicates
+                        acc0[j] += c.x;
+                        acc1[j] += c.y;
+                        acc2[j] += c.z;
+                    }
                 }
             } else if (flag) {
                 const size_t o = roff[j] + x;
-                fwd_pixel_direct<3, 5>(ip, wb + o, ab + o, bb + o, orow + x, g, rowy[j], x);
+                const Float3 c = fwd_outside_lane<R>(ip, wb + o, ab + o, bb + o, g, rowy[j], x);
+                acc0[j] += c.x;
+                acc1[j] += c.y;
+                acc2[j] += c.z;
             }
         }
+        float *orow = out + (size_t)n * 3 * plane + roff[j];
+        st_stream(orow + (unsigned)x, acc0[j]);
+        st_stream(orow + plane + (unsigned)x, acc1[j]);
+        st_stream(orow + 2 * plane + (unsigned)x, acc2[j]);
     }
 }
 
@@ -1020,22 +877,22 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
     });
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) {
+        // taps that left the tile: recomputed through clamped global gathers, overwriting what
+        // the hot loop stored for them (same lane or same wave: program order)
         const bool flag = !(mabs[j] < (float)(R + 1));
         unsigned long long todo = __ballot(flag && tx0 + (int)threadIdx.x == x);
         if (todo) {  // wave-uniform, rare
+            float *gwn = gw ? gw + nb : nullptr, *goyn = goy ? goy + nb : nullptr,
+                  *goxn = gox ? gox + nb : nullptr;
             if (__popcll(todo) <= kCoopMaxPixels) {
                 while (todo) {
                     const int b = __ffsll((long long)todo) - 1;
                     todo &= todo - 1;
-                    bwd_pixel_coop(ip, wb, ab, bb, gb_, gw ? gw + nb : nullptr,
-                                   goy ? goy + nb : nullptr, gox ? gox + nb : nullptr, g, rowy[j],
-                                   tx0 + b);
+                    bwd_outside_coop<R>(ip, wb, ab, bb, gb_, gwn, goyn, goxn, g, rowy[j], tx0 + b);
                 }
             } else if (flag) {
-                const size_t o = roff[j] + x;
-                bwd_pixel_direct<3, 5>(ip, wb + o, ab + o, bb + o, gb_ + o,
-                                       gw ? gw + nb + o : nullptr, goy ? goy + nb + o : nullptr,
-                                       gox ? gox + nb + o : nullptr, g, rowy[j], x);
+                bwd_outside_lane<R>(ip, wb, ab, bb, d[j][0], d[j][1], d[j][2], gwn, goyn, goxn, g,
+                                    rowy[j], x);
             }
         }
     }
@@ -1269,12 +1126,10 @@ int make_geom(Geom &g, int N, int C, int H, int W, int k, int d)
     return 0;
 }
 
-// Kernel structure, chosen at build time (tools/ab.py compares builds in one process):
-//   SYNTH_TAPMAJOR 0: row-major tap loop (synth_*_tiled, tile 64 x 16)
-//                  1: tap-major (synth_*_tapmajor, tile 64 x 4*SYNTH_ROWS)
-#ifndef SYNTH_TAPMAJOR
-#define SYNTH_TAPMAJOR 1
-#endif
+// Tile configuration per built radius (tools/ab.py compares builds in one process; the
+// SYNTH_* macros override the R <= 8 shape for such experiments).
+//   R <= 8 : 4 waves x 8 rows  = 64 x 32 pixels, LDS 47.9 / 55.4 / 72.1 KB, 2 workgroups per CU
+//   R = 16 : 8 waves x 4 rows  = 64 x 32 pixels, LDS 111.5 KB, 1 workgroup (8 waves) per CU
 #ifndef SYNTH_WAVES
 #define SYNTH_WAVES 4
 #endif
@@ -1284,13 +1139,20 @@ int make_geom(Geom &g, int N, int C, int H, int W, int k, int d)
 #ifndef SYNTH_OCC
 #define SYNTH_OCC 2
 #endif
-#ifndef SYNTH_BWD_TAPMAJOR
-#define SYNTH_BWD_TAPMAJOR SYNTH_TAPMAJOR
+#ifndef SYNTH_DEFAULT_RADIUS
+#define SYNTH_DEFAULT_RADIUS 8
 #endif
 
-// tile radii built for the LDS-staged kernels (TH = 16)
-constexpr int kTileTH = 16;
-constexpr int kDefaultRadius = 4;
+template <int R>
+struct TileCfg {
+    static constexpr int WAVES = SYNTH_WAVES, ROWS = SYNTH_ROWS, OCC = SYNTH_OCC;
+};
+template <>
+struct TileCfg<16> {
+    static constexpr int WAVES = 8, ROWS = 4, OCC = 2;
+};
+
+constexpr int kDefaultRadius = SYNTH_DEFAULT_RADIUS;
 
 int pick_radius(int requested)
 {
@@ -1298,7 +1160,8 @@ int pick_radius(int requested)
     if (requested < 0) requested = kDefaultRadius;
     if (requested <= 2) return 2;
     if (requested <= 4) return 4;
-    return 8;
+    if (requested <= 8) return 8;
+    return 16;
 }
 
 bool tiled_ok(const Geom &g) { return g.k == 5 && g.d == 1 && g.C == 3; }
@@ -1313,14 +1176,10 @@ template <int R>
 void launch_fwd_tiled(const float *in, const float *w, const float *oy, const float *ox, float *out,
                       const Geom &g, hipStream_t st)
 {
-#if SYNTH_TAPMAJOR
-    hipLaunchKernelGGL((synth_fwd_tapmajor<R, SYNTH_WAVES, SYNTH_ROWS, SYNTH_OCC>),
-                       pixel_grid(g, SYNTH_WAVES * SYNTH_ROWS), dim3(64, SYNTH_WAVES), 0, st, in, w, oy,
-                       ox, out, g);
-#else
-    hipLaunchKernelGGL((synth_fwd_tiled<R, kTileTH>), pixel_grid(g, kTileTH), dim3(64, 4), 0, st, in,
-                       w, oy, ox, out, g);
-#endif
+    typedef TileCfg<R> T;
+    hipLaunchKernelGGL((synth_fwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC>),
+                       pixel_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, in, w, oy, ox, out,
+                       g);
 }
 
 template <int R>
@@ -1328,23 +1187,15 @@ void launch_bwd_tiled(const float *in, const float *w, const float *oy, const fl
                       const float *gout, float *gw, float *goy, float *gox, const Geom &g,
                       hipStream_t st)
 {
-#if SYNTH_BWD_TAPMAJOR
+    typedef TileCfg<R> T;
     if (gw && goy && gox)
-        hipLaunchKernelGGL((synth_bwd_tapmajor<R, SYNTH_WAVES, SYNTH_ROWS, SYNTH_OCC, true>),
-                           pixel_grid(g, SYNTH_WAVES * SYNTH_ROWS), dim3(64, SYNTH_WAVES), 0, st, in, w,
-                           oy, ox, gout, gw, goy, gox, g);
+        hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true>),
+                           pixel_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, in, w, oy, ox,
+                           gout, gw, goy, gox, g);
     else
-        hipLaunchKernelGGL((synth_bwd_tapmajor<R, SYNTH_WAVES, SYNTH_ROWS, SYNTH_OCC, false>),
-                           pixel_grid(g, SYNTH_WAVES * SYNTH_ROWS), dim3(64, SYNTH_WAVES), 0, st, in, w,
-                           oy, ox, gout, gw, goy, gox, g);
-#else
-    if (gw && goy && gox)
-        hipLaunchKernelGGL((synth_bwd_tiled<R, kTileTH, true>), pixel_grid(g, kTileTH), dim3(64, 4), 0,
-                           st, in, w, oy, ox, gout, gw, goy, gox, g);
-    else
-        hipLaunchKernelGGL((synth_bwd_tiled<R, kTileTH, false>), pixel_grid(g, kTileTH), dim3(64, 4), 0,
-                           st, in, w, oy, ox, gout, gw, goy, gox, g);
-#endif
+        hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false>),
+                           pixel_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, in, w, oy, ox,
+                           gout, gw, goy, gox, g);
 }
 
 template <int KS>
@@ -1420,6 +1271,7 @@ int artemis_synth_forward(const float *input, const float *weight, const float *
     case 2: launch_fwd_tiled<2>(input, weight, offset_y, offset_x, output, g, st); break;
     case 4: launch_fwd_tiled<4>(input, weight, offset_y, offset_x, output, g, st); break;
     case 8: launch_fwd_tiled<8>(input, weight, offset_y, offset_x, output, g, st); break;
+    case 16: launch_fwd_tiled<16>(input, weight, offset_y, offset_x, output, g, st); break;
     default:
         for (int c0 = 0; c0 < C; c0 += 4) {
             const int ch = C - c0 < 4 ? C - c0 : 4;
@@ -1470,6 +1322,7 @@ int artemis_synth_backward(const float *input, const float *weight, const float 
         case 2: launch_bwd_tiled<2>(input, weight, offset_y, offset_x, grad_output, grad_weight, grad_offset_y, grad_offset_x, g, st); break;
         case 4: launch_bwd_tiled<4>(input, weight, offset_y, offset_x, grad_output, grad_weight, grad_offset_y, grad_offset_x, g, st); break;
         case 8: launch_bwd_tiled<8>(input, weight, offset_y, offset_x, grad_output, grad_weight, grad_offset_y, grad_offset_x, g, st); break;
+        case 16: launch_bwd_tiled<16>(input, weight, offset_y, offset_x, grad_output, grad_weight, grad_offset_y, grad_offset_x, g, st); break;
         default:
             if (k == 5 && C == 3)
                 hipLaunchKernelGGL((synth_bwd_direct<3, 5>), pixel_grid(g, 4), dim3(64, 4), 0, st, input,
@@ -1485,7 +1338,8 @@ int artemis_synth_backward(const float *input, const float *weight, const float 
     }
 
     if (grad_input) {
-        const int Rg = tiled_ok(g) ? pick_radius(tile_radius) : 0;
+        // 64-bit accumulator tiles: radius capped at 8 (75.5 KB); farther taps go to memory directly
+        const int Rg = tiled_ok(g) ? (pick_radius(tile_radius) > 8 ? 8 : pick_radius(tile_radius)) : 0;
         const int bits = count_bits_for(g);
         const bool fixed = gin_mode == ARTEMIS_SYNTH_GIN_DETERMINISTIC;
         const size_t need = ws_bytes_needed(g, gin_mode, Rg);
