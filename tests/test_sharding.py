@@ -1,0 +1,102 @@
+"""Multi-GPU path on CPU: the batch x timestep partition (host logic) and a world_size-2 gloo run in
+which each rank computes its own shard (with the CPU oracle standing in for the device op -- the
+product op has no CPU path) and the gathered result equals the single-process one."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from artemis_amd import sharding
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("n,world", [(0, 1), (1, 8), (7, 8), (8, 8), (9, 8), (64, 8), (16, 3), (5, 2)])
+def test_shard_bounds_partition(n, world):
+    covered = []
+    sizes = []
+    for r in range(world):
+        b, e = sharding.shard_bounds(n, r, world)
+        assert 0 <= b <= e <= n
+        covered += list(range(b, e))
+        sizes.append(e - b)
+    assert covered == list(range(n))           # disjoint, ordered, complete
+    assert max(sizes) - min(sizes) <= 1         # balanced
+    assert sizes == sorted(sizes, reverse=True)
+
+
+def test_shard_bounds_errors():
+    with pytest.raises(ValueError):
+        sharding.shard_bounds(4, 2, 2)
+    with pytest.raises(ValueError):
+        sharding.shard_bounds(-1, 0, 2)
+
+
+def test_interpolate_config_7_timesteps_on_8_gpus():
+    # BASELINE.json configs[3]: one 4-frame window, 7 timesteps, 8 GPUs -> one timestep per GPU
+    items = [sharding.shard_items(1, 7, r, 8) for r in range(8)]
+    assert [len(i) for i in items] == [1] * 7 + [0]
+    assert [i[0].timestep for i in items[:7]] == list(range(7))
+    # train config: batch 64 over 8 GPUs -> 8 samples each
+    assert all(len(sharding.shard_items(64, 1, r, 8)) == 8 for r in range(8))
+
+
+def test_row_strips_cover_frame():
+    strips = sharding.row_strips(2160, 8, halo=9)
+    assert strips[0][0] == 0 and strips[-1][1] == 2160
+    for (y0, y1, lo, hi), nxt in zip(strips, strips[1:] + [None]):
+        assert y1 - y0 == 270
+        assert lo <= y0 and hi >= min(y1 + 5, 2164)
+        assert 0 <= lo and hi <= 2164
+        if nxt:
+            assert nxt[0] == y1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from conftest import make_operands
+        from oracle import synth_oracle as oracle
+        N = 5  # ragged over 2 ranks: 3 + 2
+        inp, w, oy, ox, _ = make_operands(N, 3, 9, 70, regime="gauss1", seed=42)
+        mine = sharding.shard_batch([torch.from_numpy(a) for a in (inp, w, oy, ox)], rank, world)
+        b, e = sharding.shard_bounds(N, rank, world)
+        assert mine[0].shape[0] == e - b
+        local = torch.from_numpy(oracle.forward(*[t.numpy() for t in mine], 1))
+        full = sharding.gather_outputs(local, N)
+        ref = oracle.forward(inp, w, oy, ox, 1)
+        ok = np.array_equal(full.numpy(), ref)
+        # the timing reduction bench.py uses: MAX over ranks
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ok = ok and float(t) == float(world)
+        dist.barrier()
+        if rank == 0:
+            with open(out_path, "w") as f:
+                f.write("ok" if ok else "mismatch")
+        assert ok
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_shards_reassemble(tmp_path):
+    out = tmp_path / "result.txt"
+    mp.spawn(_worker, args=(2, _free_port(), str(out)), nprocs=2, join=True)
+    assert out.read_text() == "ok"
