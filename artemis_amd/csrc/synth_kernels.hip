@@ -1140,7 +1140,7 @@ int make_geom(Geom &g, int N, int C, int H, int W, int k, int d)
 #define SYNTH_OCC 2
 #endif
 #ifndef SYNTH_DEFAULT_RADIUS
-#define SYNTH_DEFAULT_RADIUS 8
+#define SYNTH_DEFAULT_RADIUS 16
 #endif
 
 template <int R>
@@ -1210,7 +1210,8 @@ void launch_fwd_direct(int ch, dim3 grid, dim3 block, hipStream_t st, const floa
     }
 }
 
-// gradInput tiles: 64 x 16 pixels, 64-bit accumulators (3 x 29 x 77 x 8 B = 53.6 KB at R = 4)
+// gradInput tiles: 64 x 16 pixels, 64-bit accumulators (3 x 29 x 77 x 8 B = 53.6 KB at R = 4,
+// 128.5 KB at R = 16: one workgroup per CU)
 template <int R, bool FIXED>
 void launch_gin_tiled(const float *w, const float *oy, const float *ox, const float *gout, float *gin,
                       unsigned char *ws, const Geom &g, int bits, hipStream_t st)
@@ -1338,8 +1339,7 @@ int artemis_synth_backward(const float *input, const float *weight, const float 
     }
 
     if (grad_input) {
-        // 64-bit accumulator tiles: radius capped at 8 (75.5 KB); farther taps go to memory directly
-        const int Rg = tiled_ok(g) ? (pick_radius(tile_radius) > 8 ? 8 : pick_radius(tile_radius)) : 0;
+        const int Rg = tiled_ok(g) ? pick_radius(tile_radius) : 0;
         const int bits = count_bits_for(g);
         const bool fixed = gin_mode == ARTEMIS_SYNTH_GIN_DETERMINISTIC;
         const size_t need = ws_bytes_needed(g, gin_mode, Rg);
@@ -1369,7 +1369,9 @@ int artemis_synth_backward(const float *input, const float *weight, const float 
             case 8: launch_gin_tiled<4, false>(weight, offset_y, offset_x, grad_output, grad_input, ws, g, bits, st); break;
             case 9: launch_gin_tiled<4, true>(weight, offset_y, offset_x, grad_output, grad_input, ws, g, bits, st); break;
             case 16: launch_gin_tiled<8, false>(weight, offset_y, offset_x, grad_output, grad_input, ws, g, bits, st); break;
-            default: launch_gin_tiled<8, true>(weight, offset_y, offset_x, grad_output, grad_input, ws, g, bits, st); break;
+            case 17: launch_gin_tiled<8, true>(weight, offset_y, offset_x, grad_output, grad_input, ws, g, bits, st); break;
+            case 32: launch_gin_tiled<16, false>(weight, offset_y, offset_x, grad_output, grad_input, ws, g, bits, st); break;
+            default: launch_gin_tiled<16, true>(weight, offset_y, offset_x, grad_output, grad_input, ws, g, bits, st); break;
             }
         } else if (!fixed) {
             if (k == 5 && C == 3)

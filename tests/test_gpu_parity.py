@@ -50,7 +50,7 @@ def run_hip(dev, inp, w, oy, ox, gout, d, radius=-1, deterministic=False, need=(
     return out.detach().cpu().numpy(), [None if x.grad is None else x.grad.cpu().numpy() for x in t]
 
 
-@pytest.mark.parametrize("radius", [-1, 0, 2, 8])
+@pytest.mark.parametrize("radius", [-1, 0, 2, 4, 8, 16])
 @pytest.mark.parametrize("name", golden_names())
 def test_golden(dev, name, radius):
     g = load_golden(name)
@@ -69,7 +69,7 @@ SHAPES = [(1, 3, 33, 70), (2, 3, 17, 129), (1, 3, 64, 64), (3, 3, 1, 1), (1, 3, 
 REGIMES = ["init", "gauss1", "gauss4", "uniform3", "clamp40", "integer"]
 
 
-@pytest.mark.parametrize("radius", [-1, 0, 2])
+@pytest.mark.parametrize("radius", [-1, 0, 2, 8])
 @pytest.mark.parametrize("regime", REGIMES)
 @pytest.mark.parametrize("shape", SHAPES)
 def test_seeded_against_oracle(dev, oracle, shape, regime, radius):
