@@ -110,11 +110,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one rank per GPU; BENCH_DIST_BACKEND=gloo (+ ranks sharing a GPU) only rehearses the
+    # multi-rank control flow on a one-GPU box
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     lib = _lib.load()  # raises if the HIP library is missing: there is no fallback
     frames = make_frames(args.batch, args.sigma, device, seed=103 + rank)
@@ -170,7 +178,7 @@ def main():
 
     ms = (t1 - t0) * 1e3 / args.steps
     if world > 1:
-        tt = torch.tensor([ms], device=device, dtype=torch.float64)
+        tt = torch.tensor([ms], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         ms = float(tt.item())
 
