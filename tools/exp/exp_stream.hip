@@ -368,6 +368,95 @@ static void ltm(const float *w, const float *oy, const float *ox, float *gw, flo
     hipLaunchKernelGGL((stream_tapmajor<LDSB, TH, BWD, NT>), dim3((W + 63) / 64, (H + TH - 1) / TH), dim3(64, 4), 0, st, w, oy, ox, gw, ga, gb, H, W);
 }
 
+// persistent tap-major with a soft global pace-maker: a wave does not start tap t+1 until every
+// wave of its iteration has finished tap t+1-D (bounded spin: purely a performance hint).
+__device__ unsigned g_prog[64 * 25];
+__global__ void zero_prog() { for (int i = threadIdx.x; i < 64 * 25; i += blockDim.x) g_prog[i] = 0; }
+
+template <int LDSB, int TH, bool BWD, int D>
+__global__ __launch_bounds__(256) void stream_tapsync(const float *__restrict__ w, const float *__restrict__ oy,
+                                                const float *__restrict__ ox, float *__restrict__ gw,
+                                                float *__restrict__ ga, float *__restrict__ gb,
+                                                int H, int W)
+{
+    __shared__ float dummy[LDSB / 4];
+    if (LDSB > 4 && threadIdx.x == 999) dummy[threadIdx.y] = 0;
+    const int wy = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int tiles_x = (W + 63) / 64, tiles_y = (H + TH - 1) / TH, ntiles = tiles_x * tiles_y;
+    const size_t plane = (size_t)H * W;
+    constexpr int ROWS = TH / 4;
+    const int G = gridDim.x;
+#pragma unroll 1
+    for (int iter = 0, tile = blockIdx.x; tile < ntiles; ++iter, tile += G) {
+        const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+        const int tx0 = txi * 64, ty0 = tyi * TH;
+        const unsigned x = min(tx0 + (int)threadIdx.x, W - 1);
+        const unsigned expected = 4u * (unsigned)min(G, ntiles - iter * G);
+        float buf[2][3 * ROWS];
+        float acc[3 * ROWS];
+#pragma unroll
+        for (int i = 0; i < 3 * ROWS; ++i) acc[i] = 0;
+        auto issue = [&](int t, float *dst) {
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) {
+                const int y = min(ty0 + wy + 4 * j, H - 1);
+                const size_t o = (size_t)y * W + (size_t)t * plane;
+                dst[3 * j] = __builtin_nontemporal_load(w + o + x);
+                dst[3 * j + 1] = __builtin_nontemporal_load(oy + o + x);
+                dst[3 * j + 2] = __builtin_nontemporal_load(ox + o + x);
+            }
+        };
+        issue(0, buf[0]);
+#pragma unroll
+        for (int t = 0; t < 25; ++t) {
+            if (t + 1 < 25) {
+                if (D > 0 && t + 1 - D >= 0) {
+                    const unsigned *slot = &g_prog[(iter & 63) * 25 + t + 1 - D];
+                    int spins = 0;
+                    while (__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected && ++spins < 2000)
+                        __builtin_amdgcn_s_sleep(4);
+                }
+                issue(t + 1, buf[(t + 1) & 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            float *c = buf[t & 1];
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) {
+                const int y = min(ty0 + wy + 4 * j, H - 1);
+                if (BWD) {
+                    const size_t o = (size_t)y * W + (size_t)t * plane;
+                    const float v0 = c[3 * j] * 1.5f, v1 = c[3 * j + 1] + c[3 * j], v2 = c[3 * j + 2] - c[3 * j];
+                    __builtin_nontemporal_store(v0, gw + o + x);
+                    __builtin_nontemporal_store(v1, ga + o + x);
+                    __builtin_nontemporal_store(v2, gb + o + x);
+                } else {
+                    acc[3 * j] += c[3 * j]; acc[3 * j + 1] += c[3 * j + 1]; acc[3 * j + 2] += c[3 * j + 2];
+                }
+            }
+            if (!BWD) {
+#pragma unroll
+                for (int i = 0; i < 3 * ROWS; ++i) asm volatile("" : "+v"(acc[i]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (D > 0 && (threadIdx.x & 63) == 0) atomicAdd(&g_prog[(iter & 63) * 25 + t], 1u);
+        }
+        if (!BWD) {
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) {
+                const int y = min(ty0 + wy + 4 * j, H - 1);
+                float *orow = gw + (size_t)y * W;
+                orow[x] = acc[3 * j]; (orow + plane)[x] = acc[3 * j + 1]; (orow + 2 * plane)[x] = acc[3 * j + 2];
+            }
+        }
+    }
+}
+template <int LDSB, int TH, bool BWD, int D>
+static void lts(int G, const float *w, const float *oy, const float *ox, float *gw, float *ga, float *gb, int H, int W, hipStream_t st)
+{
+    hipLaunchKernelGGL(zero_prog, dim3(1), dim3(256), 0, st);
+    hipLaunchKernelGGL((stream_tapsync<LDSB, TH, BWD, D>), dim3(G), dim3(64, 4), 0, st, w, oy, ox, gw, ga, gb, H, W);
+}
+
 template <int DEPTH, int LDSB, int TH>
 static void l1(const float *w, const float *oy, const float *ox, float *out, int H, int W, hipStream_t st)
 {
@@ -419,6 +508,15 @@ extern "C" int exp_runb(int variant, const float *w, const float *oy, const floa
     case 37: ltm<L4, 32, false, 3>(w, oy, ox, gw, ga, gb, H, W, st); break;
     case 38: ltm<L4, 8, false, 3>(w, oy, ox, gw, ga, gb, H, W, st); break;
     case 39: ltm<L8, 16, false, 3>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 50: lts<70000, 32, true, 0>(512, w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 51: lts<70000, 32, true, 1>(512, w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 52: lts<70000, 32, true, 2>(512, w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 53: lts<70000, 32, true, 4>(512, w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 54: lts<70000, 32, false, 0>(512, w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 55: lts<70000, 32, false, 1>(512, w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 56: lts<70000, 32, false, 2>(512, w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 57: lts<36000, 32, true, 2>(1024, w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 58: lts<36000, 32, true, 0>(1024, w, oy, ox, gw, ga, gb, H, W, st); break;
     case 40: ltm<L4, 32, true, 0>(w, oy, ox, gw, ga, gb, H, W, st); break;
     case 41: ltm<L4, 32, true, 1>(w, oy, ox, gw, ga, gb, H, W, st); break;
     case 42: ltm<L4, 32, true, 2>(w, oy, ox, gw, ga, gb, H, W, st); break;
