@@ -17,6 +17,10 @@ HIPCC_FLAGS = [
     "-fPIC",
     "-shared",
     "-munsafe-fp-atomics",  # fp32 atomicAdd -> one global_atomic_add_f32, no CAS loop
+    # contract a*b+c only where one source expression spells it (not wherever the backend finds
+    # a chance): every unrolled copy of the per-row arithmetic then rounds identically, so a pixel's
+    # bits do not depend on which row slot of a tile computed it
+    "-ffp-contract=on",
     "-Wall",
 ]
 

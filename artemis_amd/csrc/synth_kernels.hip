@@ -1105,8 +1105,10 @@ int check_launch(const char *what)
     return 0;
 }
 
-// 0 ok, 1 invalid, -1 empty problem
-int make_geom(Geom &g, int N, int C, int H, int W, int k, int d)
+// 0 ok, > 0 invalid, -1 empty problem.  Frame (in_H, in_W) and origin (org_y, org_x): the frame row
+// read by tap r of output row y is clamp(y + org_y + r*d + trunc(offset), 0, in_H - 1).
+int make_geom_ex(Geom &g, int N, int C, int H, int W, int k, int d, long long in_H, long long in_W,
+                 int org_y, int org_x)
 {
     if (N < 0 || C < 0 || H < 0 || W < 0)
         return fail(hipErrorInvalidValue, "negative dimension N=%d C=%d H=%d W=%d", N, C, H, W);
@@ -1114,16 +1116,27 @@ int make_geom(Geom &g, int N, int C, int H, int W, int k, int d)
         return fail(hipErrorInvalidValue, "filter size k=%d and dilation d=%d must be >= 1", k, d);
     if (N > 65535) return fail(hipErrorInvalidValue, "N=%d exceeds 65535 (grid.z)", N);
     const long long halo = (long long)(k - 1) * d;
-    const long long Hin = H + halo, Win = W + halo;
-    if (halo > (1 << 20) || (long long)H * W >= (1LL << 31) || Hin * Win >= (1LL << 31) ||
-        (long long)k * k >= (1 << 20))
+    if (halo > (1 << 20) || (long long)H * W >= (1LL << 31) || in_H * in_W >= (1LL << 31) ||
+        in_H >= (1LL << 31) || in_W >= (1LL << 31) || (long long)k * k >= (1 << 20))
         return fail(hipErrorInvalidValue,
-                    "plane too large: H=%d W=%d k=%d d=%d (each plane must hold < 2^31 elements)",
-                    H, W, k, d);
+                    "plane too large: H=%d W=%d k=%d d=%d frame %lld x %lld (each plane must hold "
+                    "< 2^31 elements)", H, W, k, d, in_H, in_W);
+    if (in_H < 0 || in_W < 0) return fail(hipErrorInvalidValue, "negative frame size");
+    if (org_y < -(1 << 24) || org_y > (1 << 24) || org_x < -(1 << 24) || org_x > (1 << 24))
+        return fail(hipErrorInvalidValue, "frame origin (%d, %d) out of range", org_y, org_x);
     g.N = N; g.C = C; g.H = H; g.W = W; g.k = k; g.d = d;
-    g.Hin = (int)Hin; g.Win = (int)Win; g.oy0 = 0; g.ox0 = 0;
+    g.Hin = (int)in_H; g.Win = (int)in_W; g.oy0 = org_y; g.ox0 = org_x;
     if (N == 0 || C == 0 || H == 0 || W == 0) return -1;
+    if (in_H == 0 || in_W == 0)
+        return fail(hipErrorInvalidValue, "empty frame (%lld x %lld) with a non-empty output", in_H, in_W);
     return 0;
+}
+
+// the reference layout: frame padded by (k-1)*d, origin 0 (cupy_module/synth.py:277-278)
+int make_geom(Geom &g, int N, int C, int H, int W, int k, int d)
+{
+    const long long halo = (k >= 1 && d >= 1) ? (long long)(k - 1) * d : 0;
+    return make_geom_ex(g, N, C, H, W, k, d, H + halo, W + halo, 0, 0);
 }
 
 // Tile configuration per built radius (tools/ab.py compares builds in one process; the
@@ -1256,12 +1269,10 @@ const char *artemis_synth_version(void)
 
 const char *artemis_synth_last_error(void) { return g_last_error; }
 
-int artemis_synth_forward(const float *input, const float *weight, const float *offset_y,
-                          const float *offset_x, float *output, int N, int C, int H, int W, int k,
-                          int d, int tile_radius, void *stream)
+static int run_forward(const Geom &g, int rc, const float *input, const float *weight,
+                       const float *offset_y, const float *offset_x, float *output, int tile_radius,
+                       void *stream)
 {
-    Geom g;
-    const int rc = make_geom(g, N, C, H, W, k, d);
     if (rc > 0) return rc;
     if (rc < 0) return 0;
     if (!input || !weight || !offset_y || !offset_x || !output)
@@ -1274,14 +1285,33 @@ int artemis_synth_forward(const float *input, const float *weight, const float *
     case 8: launch_fwd_tiled<8>(input, weight, offset_y, offset_x, output, g, st); break;
     case 16: launch_fwd_tiled<16>(input, weight, offset_y, offset_x, output, g, st); break;
     default:
-        for (int c0 = 0; c0 < C; c0 += 4) {
-            const int ch = C - c0 < 4 ? C - c0 : 4;
+        for (int c0 = 0; c0 < g.C; c0 += 4) {
+            const int ch = g.C - c0 < 4 ? g.C - c0 : 4;
             const dim3 grid = pixel_grid(g, 4), block(64, 4);
-            if (k == 5) launch_fwd_direct<5>(ch, grid, block, st, input, weight, offset_y, offset_x, output, g, c0);
+            if (g.k == 5) launch_fwd_direct<5>(ch, grid, block, st, input, weight, offset_y, offset_x, output, g, c0);
             else launch_fwd_direct<0>(ch, grid, block, st, input, weight, offset_y, offset_x, output, g, c0);
         }
     }
     return check_launch("artemis_synth_forward");
+}
+
+int artemis_synth_forward(const float *input, const float *weight, const float *offset_y,
+                          const float *offset_x, float *output, int N, int C, int H, int W, int k,
+                          int d, int tile_radius, void *stream)
+{
+    Geom g;
+    const int rc = make_geom(g, N, C, H, W, k, d);
+    return run_forward(g, rc, input, weight, offset_y, offset_x, output, tile_radius, stream);
+}
+
+int artemis_synth_forward_ex(const float *input, const float *weight, const float *offset_y,
+                             const float *offset_x, float *output, int N, int C, int H, int W, int k,
+                             int d, int in_H, int in_W, int org_y, int org_x, int tile_radius,
+                             void *stream)
+{
+    Geom g;
+    const int rc = make_geom_ex(g, N, C, H, W, k, d, in_H, in_W, org_y, org_x);
+    return run_forward(g, rc, input, weight, offset_y, offset_x, output, tile_radius, stream);
 }
 
 size_t artemis_synth_backward_workspace_bytes(int N, int C, int H, int W, int k, int d,
@@ -1293,15 +1323,22 @@ size_t artemis_synth_backward_workspace_bytes(int N, int C, int H, int W, int k,
     return ws_bytes_needed(g, gin_mode, tiled_ok(g) ? 1 : 0);
 }
 
-int artemis_synth_backward(const float *input, const float *weight, const float *offset_y,
-                           const float *offset_x, const float *grad_output, float *grad_input,
-                           float *grad_weight, float *grad_offset_y, float *grad_offset_x, int N,
-                           int C, int H, int W, int k, int d, int gin_mode, int tile_radius,
-                           void *workspace, size_t workspace_bytes, void *stream)
+size_t artemis_synth_backward_workspace_bytes_ex(int N, int C, int H, int W, int k, int d, int in_H,
+                                                 int in_W, int gin_mode)
 {
     Geom g;
-    const int rc = make_geom(g, N, C, H, W, k, d);
+    if (make_geom_ex(g, N, C, H, W, k, d, in_H, in_W, 0, 0) != 0) return 0;
+    return ws_bytes_needed(g, gin_mode, tiled_ok(g) ? 1 : 0);
+}
+
+static int run_backward(const Geom &g, int rc, const float *input, const float *weight,
+                        const float *offset_y, const float *offset_x, const float *grad_output,
+                        float *grad_input, float *grad_weight, float *grad_offset_y,
+                        float *grad_offset_x, int gin_mode, int tile_radius, void *workspace,
+                        size_t workspace_bytes, void *stream)
+{
     if (rc > 0) return rc;
+    const int N = g.N, C = g.C, H = g.H, W = g.W, k = g.k;
     if (gin_mode != ARTEMIS_SYNTH_GIN_ATOMIC && gin_mode != ARTEMIS_SYNTH_GIN_DETERMINISTIC)
         return fail(hipErrorInvalidValue, "artemis_synth_backward: unknown gin_mode %d", gin_mode);
     hipStream_t st = (hipStream_t)stream;
@@ -1395,6 +1432,33 @@ int artemis_synth_backward(const float *input, const float *weight, const float 
         if (e2) return e2;
     }
     return 0;
+}
+
+int artemis_synth_backward(const float *input, const float *weight, const float *offset_y,
+                           const float *offset_x, const float *grad_output, float *grad_input,
+                           float *grad_weight, float *grad_offset_y, float *grad_offset_x, int N,
+                           int C, int H, int W, int k, int d, int gin_mode, int tile_radius,
+                           void *workspace, size_t workspace_bytes, void *stream)
+{
+    Geom g;
+    const int rc = make_geom(g, N, C, H, W, k, d);
+    return run_backward(g, rc, input, weight, offset_y, offset_x, grad_output, grad_input,
+                        grad_weight, grad_offset_y, grad_offset_x, gin_mode, tile_radius, workspace,
+                        workspace_bytes, stream);
+}
+
+int artemis_synth_backward_ex(const float *input, const float *weight, const float *offset_y,
+                              const float *offset_x, const float *grad_output, float *grad_input,
+                              float *grad_weight, float *grad_offset_y, float *grad_offset_x, int N,
+                              int C, int H, int W, int k, int d, int in_H, int in_W, int org_y,
+                              int org_x, int gin_mode, int tile_radius, void *workspace,
+                              size_t workspace_bytes, void *stream)
+{
+    Geom g;
+    const int rc = make_geom_ex(g, N, C, H, W, k, d, in_H, in_W, org_y, org_x);
+    return run_backward(g, rc, input, weight, offset_y, offset_x, grad_output, grad_input,
+                        grad_weight, grad_offset_y, grad_offset_x, gin_mode, tile_radius, workspace,
+                        workspace_bytes, stream);
 }
 
 int artemis_synth_offset_radius(const float *offset_y, const float *offset_x, size_t count,

@@ -94,6 +94,54 @@ def _check_operands(input, weight, offset_y, offset_x):
         raise ValueError("weight and input batch sizes differ")
 
 
+def _launch_forward(input, weight, offset_y, offset_x, dilation, geom):
+    """geom = (N, C, H, W, k, in_H, in_W, org_y, org_x)"""
+    N, C, H, W, k, Hin, Win, oy0, ox0 = geom
+    lib = _lib.load()
+    with torch.cuda.device(input.device):
+        # the kernel writes every element: no need for the reference's new_zeros (:285)
+        output = input.new_empty(N, C, H, W)
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(lib.artemis_synth_forward_ex(
+            _ptr(input), _ptr(weight), _ptr(offset_y), _ptr(offset_x), _ptr(output),
+            N, C, H, W, k, int(dilation), Hin, Win, oy0, ox0, int(options.tile_radius), stream),
+            "artemis_synth_forward")
+    return output
+
+
+def _launch_backward(need, gradOutput, input, weight, offset_y, offset_x, dilation, geom):
+    N, C, H, W, k, Hin, Win, oy0, ox0 = geom
+    assert (gradOutput.is_contiguous() == True)
+    if not input.is_cuda:
+        raise NotImplementedError()
+    if gradOutput.dtype != torch.float32 or tuple(gradOutput.shape) != (N, C, H, W):
+        raise ValueError("gradOutput must be float32 of the forward output's shape")
+
+    lib = _lib.load()
+    with torch.cuda.device(input.device):
+        gradInput = input.new_empty(N, C, Hin, Win) if need[0] else None
+        gradWeight = input.new_empty(N, k * k, H, W) if need[1] else None
+        gradOffset_y = input.new_empty(N, k * k, H, W) if need[2] else None
+        gradOffset_x = input.new_empty(N, k * k, H, W) if need[3] else None
+
+        deterministic = options.deterministic or torch.are_deterministic_algorithms_enabled()
+        mode = _lib.GIN_DETERMINISTIC if deterministic else _lib.GIN_ATOMIC
+        workspace, ws_bytes = None, 0
+        if need[0]:
+            ws_bytes = lib.artemis_synth_backward_workspace_bytes_ex(
+                N, C, H, W, k, int(dilation), Hin, Win, mode)
+            if ws_bytes:
+                workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=input.device)
+        stream = torch.cuda.current_stream().cuda_stream
+        if any(need[:4]):
+            _lib.check(lib.artemis_synth_backward_ex(
+                _ptr(input), _ptr(weight), _ptr(offset_y), _ptr(offset_x), _ptr(gradOutput),
+                _ptr(gradInput), _ptr(gradWeight), _ptr(gradOffset_y), _ptr(gradOffset_x),
+                N, C, H, W, k, int(dilation), Hin, Win, oy0, ox0, mode, int(options.tile_radius),
+                _ptr(workspace), ws_bytes, stream), "artemis_synth_backward")
+    return gradInput, gradWeight, gradOffset_y, gradOffset_x
+
+
 class FunctionSynth(torch.autograd.Function):
     @staticmethod
     def forward(context, input, weight, offset_y, offset_x, dilation):
@@ -101,7 +149,7 @@ class FunctionSynth(torch.autograd.Function):
         context.dilation = dilation
 
         _check_operands(input, weight, offset_y, offset_x)
-        N, C, H, W, k, _, _ = _dims(input, weight, dilation)
+        N, C, H, W, k, Hin, Win = _dims(input, weight, dilation)
 
         assert (input.is_contiguous() == True)
         assert (weight.is_contiguous() == True)
@@ -111,53 +159,72 @@ class FunctionSynth(torch.autograd.Function):
         if not input.is_cuda:
             raise NotImplementedError()
 
-        lib = _lib.load()
-        with torch.cuda.device(input.device):
-            # the kernel writes every element: no need for the reference's new_zeros (:285)
-            output = input.new_empty(N, C, H, W)
-            stream = torch.cuda.current_stream().cuda_stream
-            _lib.check(lib.artemis_synth_forward(
-                _ptr(input), _ptr(weight), _ptr(offset_y), _ptr(offset_x), _ptr(output),
-                N, C, H, W, k, int(dilation), int(options.tile_radius), stream),
-                "artemis_synth_forward")
-        return output
+        return _launch_forward(input, weight, offset_y, offset_x, dilation,
+                               (N, C, H, W, k, Hin, Win, 0, 0))
 
     @staticmethod
     def backward(context, gradOutput):
         input, weight, offset_y, offset_x = context.saved_tensors
         dilation = context.dilation
         N, C, H, W, k, Hin, Win = _dims(input, weight, dilation)
+        grads = _launch_backward(context.needs_input_grad, gradOutput, input, weight, offset_y,
+                                 offset_x, dilation, (N, C, H, W, k, Hin, Win, 0, 0))
+        return (*grads, None)
 
-        assert (gradOutput.is_contiguous() == True)
-        if not input.is_cuda:
+
+class FunctionSynthFrame(torch.autograd.Function):
+    """The op on a frame of explicit geometry (``artemis_synth_forward_ex``): tap (r, s) of output
+    pixel (y, x) samples ``frame`` around ``(y + origin_y + r*d, x + origin_x + s*d)`` plus its
+    offsets, indices clamped to the frame.  ``FunctionSynth`` is ``frame`` = the padded input and
+    origin 0.  No counterpart class in the reference; it fuses what the reference composes around
+    the op (``model/chrono_synth.py:70,125-126``: ReplicationPad2d, then the op)."""
+
+    @staticmethod
+    def forward(context, frame, weight, offset_y, offset_x, dilation, origin_y, origin_x):
+        context.save_for_backward(frame, weight, offset_y, offset_x)
+        _check_operands(frame, weight, offset_y, offset_x)
+        k = int(math.sqrt(weight.size(1)))
+        assert k * k == weight.size(1), "weight.size(1) must be a square"
+        for t in (frame, weight, offset_y, offset_x):
+            assert (t.is_contiguous() == True)
+        if not frame.is_cuda:
             raise NotImplementedError()
-        if gradOutput.dtype != torch.float32 or tuple(gradOutput.shape) != (N, C, H, W):
-            raise ValueError("gradOutput must be float32 of the forward output's shape")
+        context.dilation = dilation
+        context.geom = (frame.size(0), frame.size(1), weight.size(2), weight.size(3), k,
+                        frame.size(2), frame.size(3), int(origin_y), int(origin_x))
+        return _launch_forward(frame, weight, offset_y, offset_x, dilation, context.geom)
 
-        need = context.needs_input_grad
-        lib = _lib.load()
-        with torch.cuda.device(input.device):
-            gradInput = input.new_empty(N, C, Hin, Win) if need[0] else None
-            gradWeight = input.new_empty(N, k * k, H, W) if need[1] else None
-            gradOffset_y = input.new_empty(N, k * k, H, W) if need[2] else None
-            gradOffset_x = input.new_empty(N, k * k, H, W) if need[3] else None
+    @staticmethod
+    def backward(context, gradOutput):
+        frame, weight, offset_y, offset_x = context.saved_tensors
+        grads = _launch_backward(context.needs_input_grad, gradOutput, frame, weight, offset_y,
+                                 offset_x, context.dilation, context.geom)
+        return (*grads, None, None, None)
 
-            deterministic = options.deterministic or torch.are_deterministic_algorithms_enabled()
-            mode = _lib.GIN_DETERMINISTIC if deterministic else _lib.GIN_ATOMIC
-            workspace, ws_bytes = None, 0
-            if need[0]:
-                ws_bytes = lib.artemis_synth_backward_workspace_bytes(
-                    N, C, H, W, k, int(dilation), mode)
-                if ws_bytes:
-                    workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=input.device)
-            stream = torch.cuda.current_stream().cuda_stream
-            if any(need[:4]):
-                _lib.check(lib.artemis_synth_backward(
-                    _ptr(input), _ptr(weight), _ptr(offset_y), _ptr(offset_x), _ptr(gradOutput),
-                    _ptr(gradInput), _ptr(gradWeight), _ptr(gradOffset_y), _ptr(gradOffset_x),
-                    N, C, H, W, k, int(dilation), mode, int(options.tile_radius),
-                    _ptr(workspace), ws_bytes, stream), "artemis_synth_backward")
-        return gradInput, gradWeight, gradOffset_y, gradOffset_x, None
+
+def synth_unpadded(frame, weight, offset_y, offset_x, dilation=1):
+    """``FunctionSynth.apply(ReplicationPad2d((k-1)d/2)(frame), weight, offset_y, offset_x, d)``
+    (model/chrono_synth.py:70,125-126) without materialising the padded frame: ``frame`` is
+    (N, C, H, W).  Output and tap gradients are bit-identical to padding first; the gradient
+    w.r.t. ``frame`` is what autograd through the padding would give."""
+    k = int(math.sqrt(weight.size(1)))
+    halo = (k - 1) * int(dilation)
+    if halo % 2:
+        raise ValueError("(k-1)*dilation must be even for symmetric padding")
+    if tuple(frame.shape[2:]) != tuple(weight.shape[2:]):
+        raise ValueError("frame and weight must have the same height and width")
+    return FunctionSynthFrame.apply(frame, weight, offset_y, offset_x, dilation,
+                                    -(halo // 2), -(halo // 2))
+
+
+def synth_strip(frame, weight, offset_y, offset_x, row0, dilation=1, padded=True):
+    """Rows ``[row0, row0 + weight.size(2))`` of the full-frame result: weight/offset tensors hold
+    only those rows, ``frame`` is the whole frame (replication-padded if ``padded``)."""
+    k = int(math.sqrt(weight.size(1)))
+    halo = (k - 1) * int(dilation)
+    org = 0 if padded else -(halo // 2)
+    return FunctionSynthFrame.apply(frame, weight, offset_y, offset_x, dilation,
+                                    int(row0) + org, org)
 
 
 def synth(input, weight, offset_y, offset_x, dilation=1):

@@ -89,6 +89,41 @@ int artemis_synth_backward(const float *input, const float *weight, const float 
 size_t artemis_synth_backward_workspace_bytes(int N, int C, int H, int W, int k, int d,
                                               int gin_mode);
 
+/* ---- explicit frame geometry ------------------------------------------------------------
+ * The *_ex entry points are the same kernels with the frame's size and origin passed instead
+ * of implied: `input` is (N, C, in_H, in_W) and tap (r, s) of output pixel (y, x) samples around
+ * frame coordinate
+ *        ( y + org_y + r*d + trunc(offset_y),  x + org_x + s*d + trunc(offset_x) )
+ * with all four corner indices clamped to [0, in_H-1] x [0, in_W-1] as in the reference
+ * (cupy_module/synth.py:32-35).  artemis_synth_forward/backward are the case
+ * in_H = H + (k-1)*d, in_W = W + (k-1)*d, org = 0.  Two compositions the reference makes around
+ * the kernel become single calls with no extra copy of the frame:
+ *  - the ReplicationPad2d in front of it (model/chrono_synth.py:70 and :125-126,
+ *    `moduleSynth(modulePad(frame), ...)`): pass the UNPADDED frame, in_H = H, in_W = W,
+ *    org_y = org_x = -((k-1)*d/2).  Clamping to the unpadded frame is the replication, so output
+ *    and tap gradients are bit-identical to padding first, and grad_input comes out already
+ *    folded onto the unpadded frame (the adjoint of the padding).
+ *  - row strips of one frame (4K inputs whose per-call weight/offset tensors should stay small,
+ *    or pipelining a frame against the producer of its weights): weight/offset/output tensors hold
+ *    rows [y0, y1) only (H = y1 - y0), `input` is the whole frame, org_y = y0 (+ the pad origin
+ *    above).  grad_input of a strip call covers the whole frame; strips' grad_inputs add.
+ * org_y, org_x may be negative; |org| <= 2^24. */
+int artemis_synth_forward_ex(const float *input, const float *weight, const float *offset_y,
+                             const float *offset_x, float *output, int N, int C, int H, int W, int k,
+                             int d, int in_H, int in_W, int org_y, int org_x, int tile_radius,
+                             void *stream);
+
+int artemis_synth_backward_ex(const float *input, const float *weight, const float *offset_y,
+                              const float *offset_x, const float *grad_output, float *grad_input,
+                              float *grad_weight, float *grad_offset_y, float *grad_offset_x, int N,
+                              int C, int H, int W, int k, int d, int in_H, int in_W, int org_y,
+                              int org_x, int gin_mode, int tile_radius, void *workspace,
+                              size_t workspace_bytes, void *stream);
+
+/* Workspace bytes for artemis_synth_backward_ex (grad_input is (N, C, in_H, in_W)). */
+size_t artemis_synth_backward_workspace_bytes_ex(int N, int C, int H, int W, int k, int d, int in_H,
+                                                 int in_W, int gin_mode);
+
 /* max over both offset tensors of |trunc(offset)| as one int32 written to *out_radius (device
  * memory), enqueued on `stream`: the tile_radius that would serve every tap from LDS.  `count`
  * = elements per tensor.  Helper for callers that want to size tile_radius; no reference

@@ -22,6 +22,13 @@
  *   input    (N, C, Hin, Win)   Hin = H + (k-1)*d, Win = W + (k-1)*d
  *   weight   (N, k*k, H, W)     offset_y, offset_x likewise
  *   output   (N, C, H, W)       gradLoss likewise
+ *
+ * The *_ex functions take the frame size (Hin, Win) and the frame coordinate (oy0, ox0) of
+ * output pixel (0, 0)'s first tap explicitly (the reference layout is Hin = H + (k-1)*d,
+ * oy0 = 0).  They restate two compositions the reference makes around the kernel: the
+ * ReplicationPad2d in front of it (model/chrono_synth.py:70,125: an unpadded frame with
+ * oy0 = ox0 = -(k-1)*d/2 reads the same texels, because clamping the index to the unpadded
+ * frame is the replication) and row strips of one frame (oy0 = first row of the strip).
  */
 #include <stddef.h>
 #include <stdint.h>
@@ -62,7 +69,8 @@ typedef struct {
 } tap_geom;
 
 /* Index/fraction computation shared by all four kernels:
- * cupy_module/synth.py:29-38 (fwd), :79-88 (gW), :130-138 (gAlpha), :180-188 (gBeta). */
+ * cupy_module/synth.py:29-38 (fwd), :79-88 (gW), :130-138 (gAlpha), :180-188 (gBeta).
+ * y, x: frame coordinates of the pixel's first tap (output coordinate + origin). */
 static inline tap_geom tap_geometry(float alpha, float beta, int y, int x, int row, int col,
                                     int d, int Hin, int Win)
 {
@@ -104,11 +112,10 @@ int synth_oracle_has_openmp(void)
 
 /* kernel_Synth_updateOutput, cupy_module/synth.py:16-50. One iteration per output element
  * (n, c, y, x); taps row-major; corner products summed left to right, then times w. */
-void synth_oracle_forward(const float *input, const float *weight, const float *offset_y,
-                          const float *offset_x, float *output, int N, int C, int H, int W, int k,
-                          int d)
+void synth_oracle_forward_ex(const float *input, const float *weight, const float *offset_y,
+                             const float *offset_x, float *output, int N, int C, int H, int W,
+                             int k, int d, int Hin, int Win, int oy0, int ox0)
 {
-    const int Hin = H + (k - 1) * d, Win = W + (k - 1) * d;
     const size_t plane = (size_t)H * W, iplane = (size_t)Hin * Win;
     const long rows = (long)N * C * H;
 #pragma omp parallel for schedule(static) num_threads(g_threads)
@@ -126,7 +133,8 @@ void synth_oracle_forward(const float *input, const float *weight, const float *
                     const float w = weight[t];
                     const float alpha = offset_y[t];
                     const float beta = offset_x[t];
-                    const tap_geom g = tap_geometry(alpha, beta, y, x, row, col, d, Hin, Win);
+                    const tap_geom g = tap_geometry(alpha, beta, y + oy0, x + ox0, row, col, d,
+                                                    Hin, Win);
                     const float a = g.alphaTrunc, b = g.betaTrunc;
                     dblOutput += w * (in[(size_t)g.bottom * Win + g.left] * (1 - a) * (1 - b) +
                                       in[(size_t)g.top * Win + g.left] * a * (1 - b) +
@@ -139,6 +147,14 @@ void synth_oracle_forward(const float *input, const float *weight, const float *
     }
 }
 
+void synth_oracle_forward(const float *input, const float *weight, const float *offset_y,
+                          const float *offset_x, float *output, int N, int C, int H, int W, int k,
+                          int d)
+{
+    synth_oracle_forward_ex(input, weight, offset_y, offset_x, output, N, C, H, W, k, d,
+                            H + (k - 1) * d, W + (k - 1) * d, 0, 0);
+}
+
 /* which: 0 = kernel_Synth_updateGradWeight (cupy_module/synth.py:64-99),
  *        1 = kernel_Synth_updateGradAlpha  (:114-149),
  *        2 = kernel_Synth_updateGradBeta   (:164-199).
@@ -147,9 +163,9 @@ void synth_oracle_forward(const float *input, const float *weight, const float *
  * defined. */
 static void grad_taps(int which, const float *gradLoss, const float *input, const float *weight,
                       const float *offset_y, const float *offset_x, float *grad, int N, int C,
-                      int H, int W, int k, int d)
+                      int H, int W, int k, int d, int Hin, int Win, int oy0, int ox0)
 {
-    const int Hin = H + (k - 1) * d, Win = W + (k - 1) * d, K = k * k;
+    const int K = k * k;
     const size_t plane = (size_t)H * W, iplane = (size_t)Hin * Win;
     const long rows = (long)N * K * H;
 #pragma omp parallel for schedule(static) num_threads(g_threads)
@@ -165,7 +181,8 @@ static void grad_taps(int which, const float *gradLoss, const float *input, cons
                 const float delta = gradLoss[(((size_t)n * C + depth) * H + y) * W + x];
                 const float alpha = offset_y[t];
                 const float beta = offset_x[t];
-                const tap_geom g = tap_geometry(alpha, beta, y, x, row, col, d, Hin, Win);
+                const tap_geom g = tap_geometry(alpha, beta, y + oy0, x + ox0, row, col, d, Hin,
+                                                Win);
                 const float *in = input + ((size_t)n * C + depth) * iplane;
                 const float bl = in[(size_t)g.bottom * Win + g.left];
                 const float tl = in[(size_t)g.top * Win + g.left];
@@ -188,25 +205,54 @@ static void grad_taps(int which, const float *gradLoss, const float *input, cons
     }
 }
 
+void synth_oracle_grad_weight_ex(const float *gradLoss, const float *input, const float *offset_y,
+                                 const float *offset_x, float *gradWeight, int N, int C, int H,
+                                 int W, int k, int d, int Hin, int Win, int oy0, int ox0)
+{
+    grad_taps(0, gradLoss, input, NULL, offset_y, offset_x, gradWeight, N, C, H, W, k, d, Hin, Win,
+              oy0, ox0);
+}
+
+void synth_oracle_grad_alpha_ex(const float *gradLoss, const float *input, const float *weight,
+                                const float *offset_y, const float *offset_x, float *gradOffset_y,
+                                int N, int C, int H, int W, int k, int d, int Hin, int Win, int oy0,
+                                int ox0)
+{
+    grad_taps(1, gradLoss, input, weight, offset_y, offset_x, gradOffset_y, N, C, H, W, k, d, Hin,
+              Win, oy0, ox0);
+}
+
+void synth_oracle_grad_beta_ex(const float *gradLoss, const float *input, const float *weight,
+                               const float *offset_y, const float *offset_x, float *gradOffset_x,
+                               int N, int C, int H, int W, int k, int d, int Hin, int Win, int oy0,
+                               int ox0)
+{
+    grad_taps(2, gradLoss, input, weight, offset_y, offset_x, gradOffset_x, N, C, H, W, k, d, Hin,
+              Win, oy0, ox0);
+}
+
 void synth_oracle_grad_weight(const float *gradLoss, const float *input, const float *offset_y,
                               const float *offset_x, float *gradWeight, int N, int C, int H, int W,
                               int k, int d)
 {
-    grad_taps(0, gradLoss, input, NULL, offset_y, offset_x, gradWeight, N, C, H, W, k, d);
+    synth_oracle_grad_weight_ex(gradLoss, input, offset_y, offset_x, gradWeight, N, C, H, W, k, d,
+                                H + (k - 1) * d, W + (k - 1) * d, 0, 0);
 }
 
 void synth_oracle_grad_alpha(const float *gradLoss, const float *input, const float *weight,
                              const float *offset_y, const float *offset_x, float *gradOffset_y,
                              int N, int C, int H, int W, int k, int d)
 {
-    grad_taps(1, gradLoss, input, weight, offset_y, offset_x, gradOffset_y, N, C, H, W, k, d);
+    synth_oracle_grad_alpha_ex(gradLoss, input, weight, offset_y, offset_x, gradOffset_y, N, C, H,
+                               W, k, d, H + (k - 1) * d, W + (k - 1) * d, 0, 0);
 }
 
 void synth_oracle_grad_beta(const float *gradLoss, const float *input, const float *weight,
                             const float *offset_y, const float *offset_x, float *gradOffset_x,
                             int N, int C, int H, int W, int k, int d)
 {
-    grad_taps(2, gradLoss, input, weight, offset_y, offset_x, gradOffset_x, N, C, H, W, k, d);
+    synth_oracle_grad_beta_ex(gradLoss, input, weight, offset_y, offset_x, gradOffset_x, N, C, H,
+                              W, k, d, H + (k - 1) * d, W + (k - 1) * d, 0, 0);
 }
 
 /* gradInput.  NOT in the reference: cupy_module/synth.py:333 allocates zeros and no kernel
@@ -215,11 +261,11 @@ void synth_oracle_grad_beta(const float *gradLoss, const float *input, const flo
  * (ci, cj), clamped corners included.  Accumulated in fp64 in a fixed order so it can judge
  * both the atomic and the deterministic device paths; checked in tests against autograd through
  * the torch restatement and against finite differences. Serial over pixels within a plane. */
-void synth_oracle_grad_input(const float *gradLoss, const float *weight, const float *offset_y,
-                             const float *offset_x, float *gradInput, int N, int C, int H, int W,
-                             int k, int d)
+void synth_oracle_grad_input_ex(const float *gradLoss, const float *weight, const float *offset_y,
+                                const float *offset_x, float *gradInput, int N, int C, int H,
+                                int W, int k, int d, int Hin, int Win, int oy0, int ox0)
 {
-    const int Hin = H + (k - 1) * d, Win = W + (k - 1) * d, K = k * k;
+    const int K = k * k;
     const size_t plane = (size_t)H * W, iplane = (size_t)Hin * Win;
     const long planes = (long)N * C;
 #pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads)
@@ -234,8 +280,8 @@ void synth_oracle_grad_input(const float *gradLoss, const float *weight, const f
                     for (int col = 0; col < k; ++col) {
                         const size_t t = ((size_t)n * K + (size_t)(row * k + col)) * plane +
                                          (size_t)y * W + x;
-                        const tap_geom g = tap_geometry(offset_y[t], offset_x[t], y, x, row, col,
-                                                        d, Hin, Win);
+                        const tap_geom g = tap_geometry(offset_y[t], offset_x[t], y + oy0,
+                                                        x + ox0, row, col, d, Hin, Win);
                         const double a = g.alphaTrunc, b = g.betaTrunc;
                         const double dw = delta * (double)weight[t];
                         acc[(size_t)g.bottom * Win + g.left] += dw * (1 - a) * (1 - b);
@@ -250,4 +296,12 @@ void synth_oracle_grad_input(const float *gradLoss, const float *weight, const f
         for (size_t i = 0; i < iplane; ++i) gi[i] = (float)acc[i];
         free(acc);
     }
+}
+
+void synth_oracle_grad_input(const float *gradLoss, const float *weight, const float *offset_y,
+                             const float *offset_x, float *gradInput, int N, int C, int H, int W,
+                             int k, int d)
+{
+    synth_oracle_grad_input_ex(gradLoss, weight, offset_y, offset_x, gradInput, N, C, H, W, k, d,
+                               H + (k - 1) * d, W + (k - 1) * d, 0, 0);
 }

@@ -52,8 +52,15 @@ def load():
         lib.synth_oracle_grad_alpha.argtypes = [_f32p] * 6 + six
         lib.synth_oracle_grad_beta.argtypes = [_f32p] * 6 + six
         lib.synth_oracle_grad_input.argtypes = [_f32p] * 5 + six
+        ten = [ctypes.c_int] * 10
+        lib.synth_oracle_forward_ex.argtypes = [_f32p] * 5 + ten
+        lib.synth_oracle_grad_weight_ex.argtypes = [_f32p] * 5 + ten
+        lib.synth_oracle_grad_alpha_ex.argtypes = [_f32p] * 6 + ten
+        lib.synth_oracle_grad_beta_ex.argtypes = [_f32p] * 6 + ten
+        lib.synth_oracle_grad_input_ex.argtypes = [_f32p] * 5 + ten
         for name in ("forward", "grad_weight", "grad_alpha", "grad_beta", "grad_input"):
             getattr(lib, "synth_oracle_" + name).restype = None
+            getattr(lib, "synth_oracle_" + name + "_ex").restype = None
         lib.synth_oracle_set_threads.argtypes = [ctypes.c_int]
         lib.synth_oracle_set_threads.restype = None
         lib.synth_oracle_get_threads.restype = ctypes.c_int
@@ -148,6 +155,49 @@ def backward(grad_out, input, weight, offset_y, offset_x, dilation=1, with_input
             grad_weight(grad_out, input, weight, offset_y, offset_x, dilation),
             grad_alpha(grad_out, input, weight, offset_y, offset_x, dilation),
             grad_beta(grad_out, input, weight, offset_y, offset_x, dilation))
+
+
+def _dims_ex(input, weight, dilation):
+    N, C, Hin, Win = input.shape
+    K, H, W = weight.shape[1:]
+    k = int(math.sqrt(K))
+    assert k * k == K
+    return N, C, H, W, k, int(dilation), Hin, Win
+
+
+def forward_ex(input, weight, offset_y, offset_x, dilation=1, origin=(0, 0)) -> np.ndarray:
+    """Forward on a frame of any size: tap (r, s) of output pixel (y, x) reads around frame
+    coordinate (y + origin[0] + r*d, x + origin[1] + s*d), clamped to the frame."""
+    input, weight, offset_y, offset_x = map(_f32, (input, weight, offset_y, offset_x))
+    N, C, H, W, k, d, Hin, Win = _dims_ex(input, weight, dilation)
+    out = np.zeros((N, C, H, W), np.float32)
+    load().synth_oracle_forward_ex(_ptr(input), _ptr(weight), _ptr(offset_y), _ptr(offset_x),
+                                   _ptr(out), N, C, H, W, k, d, Hin, Win, int(origin[0]),
+                                   int(origin[1]))
+    return out
+
+
+def backward_ex(grad_out, input, weight, offset_y, offset_x, dilation=1, origin=(0, 0),
+                with_input=True):
+    """(gradInput|None, gradWeight, gradOffset_y, gradOffset_x) of ``forward_ex``."""
+    grad_out, input, weight, offset_y, offset_x = map(
+        _f32, (grad_out, input, weight, offset_y, offset_x))
+    N, C, H, W, k, d, Hin, Win = _dims_ex(input, weight, dilation)
+    geo = (N, C, H, W, k, d, Hin, Win, int(origin[0]), int(origin[1]))
+    lib = load()
+    gw, ga, gb = (np.zeros_like(weight) for _ in range(3))
+    lib.synth_oracle_grad_weight_ex(_ptr(grad_out), _ptr(input), _ptr(offset_y), _ptr(offset_x),
+                                    _ptr(gw), *geo)
+    lib.synth_oracle_grad_alpha_ex(_ptr(grad_out), _ptr(input), _ptr(weight), _ptr(offset_y),
+                                   _ptr(offset_x), _ptr(ga), *geo)
+    lib.synth_oracle_grad_beta_ex(_ptr(grad_out), _ptr(input), _ptr(weight), _ptr(offset_y),
+                                  _ptr(offset_x), _ptr(gb), *geo)
+    gi = None
+    if with_input:
+        gi = np.zeros_like(input)
+        lib.synth_oracle_grad_input_ex(_ptr(grad_out), _ptr(weight), _ptr(offset_y),
+                                       _ptr(offset_x), _ptr(gi), *geo)
+    return gi, gw, ga, gb
 
 
 def forward_torch(input, weight, offset_y, offset_x, dilation=1):

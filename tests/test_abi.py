@@ -111,3 +111,29 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "_lib", None)
     with pytest.raises(_lib.SynthLibraryError, match="no fallback"):
         _lib.load()
+
+
+def test_ex_workspace_bytes_and_validation():
+    lib = _lib.load()
+    f = lib.artemis_synth_backward_workspace_bytes_ex
+    # grad_input is (N, C, in_H, in_W): unpadded 6 x 7 frame
+    assert f(2, 3, 6, 7, 5, 1, 6, 7, _lib.GIN_DETERMINISTIC) == 256 + 2 * 3 * 6 * 7 * 8
+    assert f(2, 3, 6, 7, 5, 1, 10, 11, _lib.GIN_DETERMINISTIC) == \
+        lib.artemis_synth_backward_workspace_bytes(2, 3, 6, 7, 5, 1, _lib.GIN_DETERMINISTIC)
+    assert f(2, 3, 6, 7, 5, 1, 6, 7, _lib.GIN_ATOMIC) == 256
+    # validation returns before any HIP call
+    rc = lib.artemis_synth_forward_ex(None, None, None, None, None, 1, 3, 4, 4, 5, 1, 0, 4, 0, 0,
+                                      -1, None)
+    assert rc == 1 and "empty frame" in lib.artemis_synth_last_error().decode()
+    rc = lib.artemis_synth_forward_ex(None, None, None, None, None, 1, 3, 4, 4, 5, 1, 4, 4,
+                                      1 << 25, 0, -1, None)
+    assert rc == 1 and "origin" in lib.artemis_synth_last_error().decode()
+    rc = lib.artemis_synth_forward_ex(None, None, None, None, None, 1, 3, 4, 4, 5, 1, -4, 4, 0, 0,
+                                      -1, None)
+    assert rc == 1
+    # empty output is a successful no-op whatever the frame
+    assert lib.artemis_synth_forward_ex(None, None, None, None, None, 0, 3, 4, 4, 5, 1, 4, 4, 0, 0,
+                                        -1, None) == 0
+    rc = lib.artemis_synth_backward_ex(None, None, None, None, None, None, None, None, None, 1, 3,
+                                       4, 4, 5, 1, 4, 4, -2, -2, 7, -1, None, 0, None)
+    assert rc == 1 and "gin_mode" in lib.artemis_synth_last_error().decode()

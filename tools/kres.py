@@ -28,7 +28,7 @@ def main():
         else:
             filt = a
     tmp = tempfile.mkdtemp(prefix="kres_")
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-c", "-munsafe-fp-atomics",
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-c", "-munsafe-fp-atomics", "-ffp-contract=on",
            "-I" + os.path.join(ROOT, "include"), "-save-temps", "-o", "k.o", SRC] + extra
     r = subprocess.run(cmd, cwd=tmp, capture_output=True, text=True)
     if r.returncode:
