@@ -499,12 +499,14 @@ __device__ __forceinline__ Float3 fwd_outside_lane(const float *__restrict__ ip,
 }
 
 // One tap of the fused backward through clamped global gathers; o = element offset of
-// (tap, y, x) in the sample's 25-plane tensors.
-__device__ __forceinline__ void bwd_tap_global(const float *__restrict__ ip, const Geom &g, float wv,
-                                               float a, float b, float d0, float d1, float d2, int yb,
-                                               int xb, float *__restrict__ gwn,
-                                               float *__restrict__ goyn, float *__restrict__ goxn,
-                                               size_t o)
+// (tap, y, x) in the sample's 25-plane tensors.  The three gradients are stored times `scale`
+// (the occlusion weight in the fused head, 1 otherwise); returns w * (unscaled gradWeight), the
+// tap's share of the occlusion gradient.
+__device__ __forceinline__ float bwd_tap_global(const float *__restrict__ ip, const Geom &g, float wv,
+                                                float a, float b, float d0, float d1, float d2, int yb,
+                                                int xb, float *__restrict__ gwn,
+                                                float *__restrict__ goyn, float *__restrict__ goxn,
+                                                size_t o, float scale)
 {
     const size_t iplane = (size_t)g.Hin * g.Win;
     const TapIdx ti = tap_index(g, a, b, yb, xb);
@@ -515,45 +517,56 @@ __device__ __forceinline__ void bwd_tap_global(const float *__restrict__ ip, con
     const float ptr_ = d0 * p0[ti.tr] + d1 * p1[ti.tr] + d2 * p2[ti.tr];
     const float dlt = ptl - pbl, drt = ptr_ - pbr;
     const float lft = pbl + ti.fa * dlt, rgt = pbr + ti.fa * drt, across = rgt - lft;
-    if (gwn) gwn[o] = lft + ti.fb * across;
-    if (goyn) goyn[o] = wv * (dlt + ti.fb * (drt - dlt));
-    if (goxn) goxn[o] = wv * across;
+    const float gwr = lft + ti.fb * across;
+    const float gar = wv * (dlt + ti.fb * (drt - dlt));
+    const float gbr = wv * across;
+    if (gwn) gwn[o] = scale * gwr;
+    if (goyn) goyn[o] = scale * gar;
+    if (goxn) goxn[o] = scale * gbr;
+    return wv * gwr;
 }
 
 // Out-of-tile taps of pixel (y, xs) recomputed and stored by the whole wave.
 // gn: the sample's gradOutput planes; gwn/goyn/goxn: tap 0 of the sample's gradient planes.
+// Returns (in every lane) the sum over those taps of w * unscaled gradWeight.
 template <int R>
-__device__ __forceinline__ void bwd_outside_coop(const float *__restrict__ ip,
-                                                 const float *__restrict__ wb,
-                                                 const float *__restrict__ ab,
-                                                 const float *__restrict__ bb,
-                                                 const float *__restrict__ gn, float *__restrict__ gwn,
-                                                 float *__restrict__ goyn, float *__restrict__ goxn,
-                                                 const Geom &g, int y, int xs)
+__device__ __forceinline__ float bwd_outside_coop(const float *__restrict__ ip,
+                                                  const float *__restrict__ wb,
+                                                  const float *__restrict__ ab,
+                                                  const float *__restrict__ bb,
+                                                  const float *__restrict__ gn, float *__restrict__ gwn,
+                                                  float *__restrict__ goyn, float *__restrict__ goxn,
+                                                  const Geom &g, int y, int xs, float scale,
+                                                  bool want_sum)
 {
     const int l = threadIdx.x & 63;
-    if (l >= 25) return;
-    const size_t plane = (size_t)g.H * g.W;
-    const size_t pix = (size_t)y * g.W + xs;
-    const size_t o = (size_t)l * plane + pix;
-    const float a = ab[o], b = bb[o];
-    if (tap_in_tile<R>(a, b)) return;
-    const int r = l / 5, s = l - 5 * r;
-    bwd_tap_global(ip, g, wb[o], a, b, gn[pix], gn[plane + pix], gn[2 * plane + pix], y + g.oy0 + r,
-                   xs + g.ox0 + s, gwn, goyn, goxn, o);
+    float c = 0.f;
+    if (l < 25) {
+        const size_t plane = (size_t)g.H * g.W;
+        const size_t pix = (size_t)y * g.W + xs;
+        const size_t o = (size_t)l * plane + pix;
+        const float a = ab[o], b = bb[o];
+        if (!tap_in_tile<R>(a, b)) {
+            const int r = l / 5, s = l - 5 * r;
+            c = bwd_tap_global(ip, g, wb[o], a, b, gn[pix], gn[plane + pix], gn[2 * plane + pix],
+                               y + g.oy0 + r, xs + g.ox0 + s, gwn, goyn, goxn, o, scale);
+        }
+    }
+    return want_sum ? wave_sum(c) : 0.f;
 }
 
 template <int R>
-__device__ __forceinline__ void bwd_outside_lane(const float *__restrict__ ip,
-                                                 const float *__restrict__ wb,
-                                                 const float *__restrict__ ab,
-                                                 const float *__restrict__ bb, float d0, float d1,
-                                                 float d2, float *__restrict__ gwn,
-                                                 float *__restrict__ goyn, float *__restrict__ goxn,
-                                                 const Geom &g, int y, int x)
+__device__ __forceinline__ float bwd_outside_lane(const float *__restrict__ ip,
+                                                  const float *__restrict__ wb,
+                                                  const float *__restrict__ ab,
+                                                  const float *__restrict__ bb, float d0, float d1,
+                                                  float d2, float *__restrict__ gwn,
+                                                  float *__restrict__ goyn, float *__restrict__ goxn,
+                                                  const Geom &g, int y, int x, float scale)
 {
     const size_t plane = (size_t)g.H * g.W;
     const size_t pix = (size_t)y * g.W + x;
+    float c = 0.f;
 #pragma unroll 1
     for (int r = 0; r < 5; ++r) {
 #pragma unroll
@@ -561,10 +574,11 @@ __device__ __forceinline__ void bwd_outside_lane(const float *__restrict__ ip,
             const size_t o = (size_t)(r * 5 + s) * plane + pix;
             const float a = ab[o], b = bb[o];
             if (!tap_in_tile<R>(a, b))
-                bwd_tap_global(ip, g, wb[o], a, b, d0, d1, d2, y + g.oy0 + r, x + g.ox0 + s, gwn, goyn,
-                               goxn, o);
+                c += bwd_tap_global(ip, g, wb[o], a, b, d0, d1, d2, y + g.oy0 + r, x + g.ox0 + s, gwn,
+                                    goyn, goxn, o, scale);
         }
     }
+    return c;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -676,10 +690,44 @@ __device__ __forceinline__ float track_abs(float m, float a, float b)
     return fmaxf(m, fmaxf(fabsf(a), fabsf(b)));
 }
 
-template <int R, int WAVES, int ROWS, int OCC>
+// The fused ChronoSynth head (HEAD = true; model/chrono_synth.py:114-129) runs the same body once
+// per context frame inside the workgroup: frame f's tile is staged, its 25 taps are applied with
+// the weights/offsets of slice [n, f] of the 5-D tensors read in place, and the result is folded
+// into  out = sum_f occ[n, f] * S_f  in registers, in the reference's order (product rounded,
+// then added: `occ * moduleSynth(...)`, Python `sum`), so the output has the bits of the
+// composition without its intermediate tensors.
+constexpr int kMaxFrames = 8;
+
+// Inside the head's frame loop every per-tap address (tap * plane + row offset: 200 wave-uniform
+// 64-bit values) is loop-invariant, and LLVM hoists them all out of the loop and then spills
+// them.  Passing the two ingredients through an empty asm once per frame makes them opaque, so
+// the addresses are formed where they are used, as in the single-frame kernels.
+__device__ __forceinline__ size_t per_frame(size_t v)
+{
+    asm volatile("" : "+s"(v));
+    return v;
+}
+
+// ... and the rare fix-up's 25 per-tap addresses of each row (lane-dependent) are hoisted to the
+// top of the frame iteration and spilled across the hot loop unless the lane's column is made
+// opaque inside the fix-up branch.
+__device__ __forceinline__ int in_branch(int v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+struct HeadArgs {
+    const float *frame[kMaxFrames];  // T frames, each (N, 3, Hin, Win)
+    const float *occ;                // (N, T, H, W)
+    float *gocc;                     // backward only: (N, T, H, W) or null
+    int T;
+};
+
+template <int R, int WAVES, int ROWS, int OCC, bool HEAD>
 __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
     const float *__restrict__ in, const float *__restrict__ w, const float *__restrict__ oy,
-    const float *__restrict__ ox, float *__restrict__ out, Geom g)
+    const float *__restrict__ ox, float *__restrict__ out, Geom g, HeadArgs ha)
 {
     constexpr int TH = WAVES * ROWS;
     constexpr int LW = TileShape<R, TH>::LW, LH = TileShape<R, TH>::LH;
@@ -689,119 +737,157 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
     const int wy = __builtin_amdgcn_readfirstlane(threadIdx.y);
     const int tid = wy * 64 + threadIdx.x;
     const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
-    const float *ip = in + (size_t)n * 3 * iplane;
     // A lane past the right edge acts as the last image column (same operands, same arithmetic,
     // same stores as that column's owner), like the rows below: no lane ever retires on its own,
     // so wave-wide operations in the fix-up see all 64 lanes.
     const int x = min(tx0 + (int)threadIdx.x, g.W - 1), px = x - tx0;
     const bool active = ty0 + wy < g.H;  // wave-uniform
-    const float *wb = w + (size_t)n * 25 * plane, *ab = oy + (size_t)n * 25 * plane,
-                *bb = ox + (size_t)n * 25 * plane;
 
     // A row past the bottom edge is replaced by the last image row: the wave then recomputes
     // and re-stores exactly what that row's owner stores (same operands, same arithmetic), which
     // keeps the unrolled body free of per-row branches.
     int rowy[ROWS];
     size_t roff[ROWS];
+    int rowbase[ROWS];
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) {
         rowy[j] = min(ty0 + wy + WAVES * j, g.H - 1);
         roff[j] = (size_t)rowy[j] * g.W;
-    }
-
-    // first tap of this lane's pixels: issued before the tile fill so the stream is already in
-    // flight while the tile is staged
-    TapCol<ROWS> cur;
-    if (active) load_tap_col<ROWS>(cur, wb, ab, bb, plane, 0, roff, (unsigned)x);
-
-    fill_tile_n<R, TH, 64 * WAVES>(tile, ip, g, ty0 + g.oy0 - R, tx0 + g.ox0 - R, tid);
-    __syncthreads();
-    if (!active) return;
-
-    int rowbase[ROWS];
-    float acc0[ROWS], acc1[ROWS], acc2[ROWS];
-    float mabs[ROWS];
-#pragma unroll
-    for (int j = 0; j < ROWS; ++j) {
         rowbase[j] = ((rowy[j] - ty0 + R) * LW + px + R) * 16;
-        acc0[j] = acc1[j] = acc2[j] = 0.f;
-        mabs[j] = 0.f;
     }
-    static_for<0, 25>([&](auto tc) {
-        constexpr int t = decltype(tc)::value;
-        constexpr int r = t / 5, s = t % 5;
-        TapCol<ROWS> nxt;
-        if (t < 24) load_tap_col<ROWS>(nxt, wb, ab, bb, plane, t + 1, roff, (unsigned)x);
-        __builtin_amdgcn_sched_barrier(0);
+    float res0[ROWS], res1[ROWS], res2[ROWS];  // HEAD: the running sum over frames
 #pragma unroll
-        for (int j = 0; j < ROWS; ++j) {
-            float wv = cur.w[j];
-            const float a = cur.a[j], b = cur.b[j];
-            const int ia = (int)a, ib = (int)b;
-            const float fa = a - (float)ia, fb = b - (float)ib;
-            mabs[j] = track_abs(mabs[j], a, b);
-            const Corners q = tile_corners_at<R, TH, r * LW + s>(ltile, ia, ib, rowbase[j]);
-            const float ga = 1.f - fa, gb = 1.f - fb;
-            const float c00 = ga * gb, c10 = fa * gb, c01 = ga * fb, c11 = fa * fb;
-            wv = tap_in_tile<R>(a, b) ? wv : 0.f;  // a far tap is added by the fix-up instead
-            acc0[j] += wv * (q.bl.x * c00 + q.tl.x * c10 + q.br.x * c01 + q.tr.x * c11);
-            acc1[j] += wv * (q.bl.y * c00 + q.tl.y * c10 + q.br.y * c01 + q.tr.y * c11);
-            acc2[j] += wv * (q.bl.z * c00 + q.tl.z * c10 + q.br.z * c01 + q.tr.z * c11);
-            // Pin the arithmetic in place: instruction selection otherwise floats the chain-free
-            // FMAs to the end of the unrolled block, keeping every LDS result of the pixel live
-            // (512 VGPRs or spills).  The sched_barrier bounds the LDS results in flight to
-            // kRowGroup rows (16 VGPRs each).
-            asm volatile("" : "+v"(acc0[j]), "+v"(acc1[j]), "+v"(acc2[j]), "+v"(mabs[j]));
-            if (j % kRowGroup == kRowGroup - 1) __builtin_amdgcn_sched_barrier(0);
+    for (int j = 0; j < ROWS; ++j) res0[j] = res1[j] = res2[j] = 0.f;
+
+    const int T = HEAD ? ha.T : 1;
+    for (int f = 0; f < T; ++f) {
+        size_t pl = plane, rf[ROWS];
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) rf[j] = roff[j];
+        if constexpr (HEAD) {
+            pl = per_frame(pl);
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) rf[j] = per_frame(rf[j]);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        cur = nxt;
-    });
+        const float *ip = (HEAD ? ha.frame[f] : in) + (size_t)n * 3 * iplane;
+        const size_t nb = ((size_t)n * T + f) * 25 * pl;
+        const float *wb = w + nb, *ab = oy + nb, *bb = ox + nb;
+
+        // first tap of this lane's pixels: issued before the tile fill so the stream is already
+        // in flight while the tile is staged
+        TapCol<ROWS> cur;
+        float occv[ROWS];
+        if (active) {
+            load_tap_col<ROWS>(cur, wb, ab, bb, pl, 0, rf, (unsigned)x);
+            if constexpr (HEAD) {
+                const float *op = ha.occ + ((size_t)n * T + f) * pl;
 #pragma unroll
-    for (int j = 0; j < ROWS; ++j) {
-        // taps that left the tile are added through clamped global gathers
-        const bool flag = !(mabs[j] < (float)(R + 1));
-        unsigned long long todo = __ballot(flag && tx0 + (int)threadIdx.x == x);
-        if (todo) {  // wave-uniform, rare
-            if (__popcll(todo) <= kCoopMaxPixels) {
-                while (todo) {
-                    const int b = __ffsll((long long)todo) - 1;
-                    todo &= todo - 1;
-                    const Float3 c = fwd_outside_coop<R>(ip, wb, ab, bb, g, rowy[j], tx0 + b);
-                    if (x == tx0 + b) {  // the owner and its right-edge duplicates
-                        acc0[j] += c.x;
-                        acc1[j] += c.y;
-                        acc2[j] += c.z;
-                    }
-                }
-            } else if (flag) {
-                const size_t o = roff[j] + x;
-                const Float3 c = fwd_outside_lane<R>(ip, wb + o, ab + o, bb + o, g, rowy[j], x);
-                acc0[j] += c.x;
-                acc1[j] += c.y;
-                acc2[j] += c.z;
+                for (int j = 0; j < ROWS; ++j) occv[j] = ld_stream(op + rf[j] + (unsigned)x);
             }
         }
+
+        if (HEAD && f > 0) __syncthreads();  // every wave is done with the previous frame's tile
+        fill_tile_n<R, TH, 64 * WAVES>(tile, ip, g, ty0 + g.oy0 - R, tx0 + g.ox0 - R, tid);
+        __syncthreads();
+        if (!active) {
+            if constexpr (HEAD) continue;  // keeps taking part in the fills and barriers
+            else return;
+        }
+
+        float acc0[ROWS], acc1[ROWS], acc2[ROWS];
+        float mabs[ROWS];
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {
+            acc0[j] = acc1[j] = acc2[j] = 0.f;
+            mabs[j] = 0.f;
+        }
+        static_for<0, 25>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            constexpr int r = t / 5, s = t % 5;
+            TapCol<ROWS> nxt;
+            if (t < 24) load_tap_col<ROWS>(nxt, wb, ab, bb, pl, t + 1, rf, (unsigned)x);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) {
+                float wv = cur.w[j];
+                const float a = cur.a[j], b = cur.b[j];
+                const int ia = (int)a, ib = (int)b;
+                const float fa = a - (float)ia, fb = b - (float)ib;
+                mabs[j] = track_abs(mabs[j], a, b);
+                const Corners q = tile_corners_at<R, TH, r * LW + s>(ltile, ia, ib, rowbase[j]);
+                const float ga = 1.f - fa, gb = 1.f - fb;
+                const float c00 = ga * gb, c10 = fa * gb, c01 = ga * fb, c11 = fa * fb;
+                wv = tap_in_tile<R>(a, b) ? wv : 0.f;  // a far tap is added by the fix-up instead
+                acc0[j] += wv * (q.bl.x * c00 + q.tl.x * c10 + q.br.x * c01 + q.tr.x * c11);
+                acc1[j] += wv * (q.bl.y * c00 + q.tl.y * c10 + q.br.y * c01 + q.tr.y * c11);
+                acc2[j] += wv * (q.bl.z * c00 + q.tl.z * c10 + q.br.z * c01 + q.tr.z * c11);
+                // Pin the arithmetic in place: instruction selection otherwise floats the
+                // chain-free FMAs to the end of the unrolled block, keeping every LDS result of
+                // the pixel live (512 VGPRs or spills).  The sched_barrier bounds the LDS results
+                // in flight to kRowGroup rows (16 VGPRs each).
+                asm volatile("" : "+v"(acc0[j]), "+v"(acc1[j]), "+v"(acc2[j]), "+v"(mabs[j]));
+                if (j % kRowGroup == kRowGroup - 1) __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
+        });
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {
+            // taps that left the tile are added through clamped global gathers
+            const bool flag = !(mabs[j] < (float)(R + 1));
+            unsigned long long todo = __ballot(flag && tx0 + (int)threadIdx.x == x);
+            if (todo) {  // wave-uniform, rare
+                if (__popcll(todo) <= kCoopMaxPixels) {
+                    while (todo) {
+                        const int b = __ffsll((long long)todo) - 1;
+                        todo &= todo - 1;
+                        const Float3 c = fwd_outside_coop<R>(ip, wb, ab, bb, g, rowy[j], tx0 + b);
+                        if (x == tx0 + b) {  // the owner and its right-edge duplicates
+                            acc0[j] += c.x;
+                            acc1[j] += c.y;
+                            acc2[j] += c.z;
+                        }
+                    }
+                } else if (flag) {
+                    const size_t o = rf[j] + x;
+                    const Float3 c = fwd_outside_lane<R>(ip, wb + o, ab + o, bb + o, g, rowy[j], x);
+                    acc0[j] += c.x;
+                    acc1[j] += c.y;
+                    acc2[j] += c.z;
+                }
+            }
+            if constexpr (HEAD) {
+                // occ * S_f rounded to fp32, then added: the reference's two separate ops
+                const float p0 = occv[j] * acc0[j], p1 = occv[j] * acc1[j], p2 = occv[j] * acc2[j];
+                res0[j] = res0[j] + p0;
+                res1[j] = res1[j] + p1;
+                res2[j] = res2[j] + p2;
+            } else {
+                res0[j] = acc0[j];
+                res1[j] = acc1[j];
+                res2[j] = acc2[j];
+            }
+        }
+    }
+    if (HEAD && !active) return;
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
         float *orow = out + (size_t)n * 3 * plane + roff[j];
-        st_stream(orow + (unsigned)x, acc0[j]);
-        st_stream(orow + plane + (unsigned)x, acc1[j]);
-        st_stream(orow + 2 * plane + (unsigned)x, acc2[j]);
+        st_stream(orow + (unsigned)x, res0[j]);
+        st_stream(orow + plane + (unsigned)x, res1[j]);
+        st_stream(orow + 2 * plane + (unsigned)x, res2[j]);
     }
 }
 
-// ALL: the three gradients are all requested (the model's case).
-// Per tap, with P_q = sum_c gradOut_c * corner_q(c)  (q = bl, tl, br, tr):
-//   L = P_bl + fa (P_tl - P_bl),  Rt = P_br + fa (P_tr - P_br)      (vertical lerps)
-//   gradWeight   = L + fb (Rt - L)
-//   gradOffset_x = w (Rt - L)                                        (= d/d beta of the blend)
-//   gradOffset_y = w ((P_tl - P_bl) + fb ((P_tr - P_br) - (P_tl - P_bl)))
-// which is the reference's formulas (cupy_module/synth.py:90-95, :140-145, :190-195) with the
-// common subexpressions shared: 22 flops per tap instead of 32.
-template <int R, int WAVES, int ROWS, int OCC, bool ALL>
+// HEAD = true: the fused ChronoSynth head's backward.  gradOutput is the gradient of
+// out = sum_f occ_f * S_f; per frame the kernel forms the unscaled tap gradients from it, stores
+// them times occ_f into slice [n, f] of the 5-D gradient tensors in place, and accumulates
+// gocc[n, f] = sum_c gradOutput_c * S_f,c = sum_t w_t * (unscaled gradWeight_t) in registers.
+template <int R, int WAVES, int ROWS, int OCC, bool ALL, bool HEAD>
 __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
     const float *__restrict__ in, const float *__restrict__ w, const float *__restrict__ oy,
     const float *__restrict__ ox, const float *__restrict__ gout, float *__restrict__ gw,
-    float *__restrict__ goy, float *__restrict__ gox, Geom g)
+    float *__restrict__ goy, float *__restrict__ gox, Geom g, HeadArgs ha)
 {
     constexpr int TH = WAVES * ROWS;
     constexpr int LW = TileShape<R, TH>::LW, LH = TileShape<R, TH>::LH;
@@ -811,88 +897,140 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
     const int wy = __builtin_amdgcn_readfirstlane(threadIdx.y);
     const int tid = wy * 64 + threadIdx.x;
     const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
-    const float *ip = in + (size_t)n * 3 * iplane;
     // lanes past the right edge duplicate the last image column (see forward)
     const int x = min(tx0 + (int)threadIdx.x, g.W - 1), px = x - tx0;
     const bool active = ty0 + wy < g.H;  // wave-uniform
-    const size_t nb = (size_t)n * 25 * plane;
-    const float *wb = w + nb, *ab = oy + nb, *bb = ox + nb;
 
     int rowy[ROWS];  // rows past the bottom edge duplicate the last image row (see forward)
     size_t roff[ROWS];
+    int rowbase[ROWS];
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) {
         rowy[j] = min(ty0 + wy + WAVES * j, g.H - 1);
         roff[j] = (size_t)rowy[j] * g.W;
-    }
-
-    TapCol<ROWS> cur;
-    if (active) load_tap_col<ROWS>(cur, wb, ab, bb, plane, 0, roff, (unsigned)x);
-
-    fill_tile_n<R, TH, 64 * WAVES>(tile, ip, g, ty0 + g.oy0 - R, tx0 + g.ox0 - R, tid);
-    __syncthreads();
-    if (!active) return;
-
-    int rowbase[ROWS];
-    float d[ROWS][3];
-    float mabs[ROWS];
-    const float *gb_ = gout + (size_t)n * 3 * plane;
-#pragma unroll
-    for (int j = 0; j < ROWS; ++j) {
         rowbase[j] = ((rowy[j] - ty0 + R) * LW + px + R) * 16;
-        d[j][0] = ld_stream(gb_ + roff[j] + (unsigned)x);
-        d[j][1] = ld_stream(gb_ + plane + roff[j] + (unsigned)x);
-        d[j][2] = ld_stream(gb_ + 2 * plane + roff[j] + (unsigned)x);
-        mabs[j] = 0.f;
     }
-    static_for<0, 25>([&](auto tc) {
-        constexpr int t = decltype(tc)::value;
-        constexpr int r = t / 5, s = t % 5;
-        TapCol<ROWS> nxt;
-        if (t < 24) load_tap_col<ROWS>(nxt, wb, ab, bb, plane, t + 1, roff, (unsigned)x);
-        __builtin_amdgcn_sched_barrier(0);
+    const float *gb_ = gout + (size_t)n * 3 * plane;
+    float d[ROWS][3];
+
+    const int T = HEAD ? ha.T : 1;
+    for (int f = 0; f < T; ++f) {
+        size_t pl = plane, rf[ROWS];
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) rf[j] = roff[j];
+        if constexpr (HEAD) {
+            pl = per_frame(pl);
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) rf[j] = per_frame(rf[j]);
+        }
+        const float *ip = (HEAD ? ha.frame[f] : in) + (size_t)n * 3 * iplane;
+        const size_t nb = ((size_t)n * T + f) * 25 * pl;
+        const float *wb = w + nb, *ab = oy + nb, *bb = ox + nb;
+
+        TapCol<ROWS> cur;
+        float occv[ROWS], gocc[ROWS];
+        if (active) {
+            load_tap_col<ROWS>(cur, wb, ab, bb, pl, 0, rf, (unsigned)x);
+            if constexpr (HEAD) {
+                const float *op = ha.occ + ((size_t)n * T + f) * pl;
+#pragma unroll
+                for (int j = 0; j < ROWS; ++j) {
+                    occv[j] = ld_stream(op + rf[j] + (unsigned)x);
+                    gocc[j] = 0.f;
+                }
+            }
+        }
+
+        if (HEAD && f > 0) __syncthreads();  // every wave is done with the previous frame's tile
+        fill_tile_n<R, TH, 64 * WAVES>(tile, ip, g, ty0 + g.oy0 - R, tx0 + g.ox0 - R, tid);
+        __syncthreads();
+        if (!active) {
+            if constexpr (HEAD) continue;
+            else return;
+        }
+
+        float mabs[ROWS];
+        if (f == 0) {  // gradOutput is the same for every frame of the head
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) {
+                d[j][0] = ld_stream(gb_ + rf[j] + (unsigned)x);
+                d[j][1] = ld_stream(gb_ + pl + rf[j] + (unsigned)x);
+                d[j][2] = ld_stream(gb_ + 2 * pl + rf[j] + (unsigned)x);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) mabs[j] = 0.f;
+        static_for<0, 25>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            constexpr int r = t / 5, s = t % 5;
+            TapCol<ROWS> nxt;
+            if (t < 24) load_tap_col<ROWS>(nxt, wb, ab, bb, pl, t + 1, rf, (unsigned)x);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) {
+                const float wv = cur.w[j], a = cur.a[j], b = cur.b[j];
+                const int ia = (int)a, ib = (int)b;
+                const float fa = a - (float)ia, fb = b - (float)ib;
+                mabs[j] = track_abs(mabs[j], a, b);
+                const Corners q = tile_corners_at<R, TH, r * LW + s>(ltile, ia, ib, rowbase[j]);
+                const float pbl = d[j][0] * q.bl.x + d[j][1] * q.bl.y + d[j][2] * q.bl.z;
+                const float ptl = d[j][0] * q.tl.x + d[j][1] * q.tl.y + d[j][2] * q.tl.z;
+                const float pbr = d[j][0] * q.br.x + d[j][1] * q.br.y + d[j][2] * q.br.z;
+                const float ptr_ = d[j][0] * q.tr.x + d[j][1] * q.tr.y + d[j][2] * q.tr.z;
+                const float dl = ptl - pbl, dr = ptr_ - pbr;
+                const float lft = pbl + fa * dl, rgt = pbr + fa * dr;
+                const float across = rgt - lft;
+                const size_t o = nb + (size_t)t * pl + rf[j];
+                if constexpr (HEAD) {
+                    const float gwr = lft + fb * across;
+                    const float gar = wv * (dl + fb * (dr - dl));
+                    const float gbr = wv * across;
+                    // a far tap's share comes from the fix-up, which also overwrites its stores
+                    gocc[j] += (tap_in_tile<R>(a, b) ? wv : 0.f) * gwr;
+                    if (ALL || gw) st_stream(gw + o + (unsigned)x, occv[j] * gwr);
+                    if (ALL || goy) st_stream(goy + o + (unsigned)x, occv[j] * gar);
+                    if (ALL || gox) st_stream(gox + o + (unsigned)x, occv[j] * gbr);
+                    asm volatile("" : "+v"(mabs[j]), "+v"(gocc[j]));
+                } else {
+                    if (ALL || gw) st_stream(gw + o + (unsigned)x, lft + fb * across);
+                    if (ALL || goy) st_stream(goy + o + (unsigned)x, wv * (dl + fb * (dr - dl)));
+                    if (ALL || gox) st_stream(gox + o + (unsigned)x, wv * across);
+                    asm volatile("" : "+v"(mabs[j]));
+                }
+                if (j % kRowGroup == kRowGroup - 1) __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
+        });
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) {
-            const float wv = cur.w[j], a = cur.a[j], b = cur.b[j];
-            const int ia = (int)a, ib = (int)b;
-            const float fa = a - (float)ia, fb = b - (float)ib;
-            mabs[j] = track_abs(mabs[j], a, b);
-            const Corners q = tile_corners_at<R, TH, r * LW + s>(ltile, ia, ib, rowbase[j]);
-            const float pbl = d[j][0] * q.bl.x + d[j][1] * q.bl.y + d[j][2] * q.bl.z;
-            const float ptl = d[j][0] * q.tl.x + d[j][1] * q.tl.y + d[j][2] * q.tl.z;
-            const float pbr = d[j][0] * q.br.x + d[j][1] * q.br.y + d[j][2] * q.br.z;
-            const float ptr_ = d[j][0] * q.tr.x + d[j][1] * q.tr.y + d[j][2] * q.tr.z;
-            const float dl = ptl - pbl, dr = ptr_ - pbr;
-            const float lft = pbl + fa * dl, rgt = pbr + fa * dr;
-            const float across = rgt - lft;
-            const size_t o = nb + (size_t)t * plane + roff[j];
-            if (ALL || gw) st_stream(gw + o + (unsigned)x, lft + fb * across);
-            if (ALL || goy) st_stream(goy + o + (unsigned)x, wv * (dl + fb * (dr - dl)));
-            if (ALL || gox) st_stream(gox + o + (unsigned)x, wv * across);
-            asm volatile("" : "+v"(mabs[j]));
-            if (j % kRowGroup == kRowGroup - 1) __builtin_amdgcn_sched_barrier(0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        cur = nxt;
-    });
-#pragma unroll
-    for (int j = 0; j < ROWS; ++j) {
-        // taps that left the tile: recomputed through clamped global gathers, overwriting what
-        // the hot loop stored for them (same lane or same wave: program order)
-        const bool flag = !(mabs[j] < (float)(R + 1));
-        unsigned long long todo = __ballot(flag && tx0 + (int)threadIdx.x == x);
-        if (todo) {  // wave-uniform, rare
-            float *gwn = gw ? gw + nb : nullptr, *goyn = goy ? goy + nb : nullptr,
-                  *goxn = gox ? gox + nb : nullptr;
-            if (__popcll(todo) <= kCoopMaxPixels) {
-                while (todo) {
-                    const int b = __ffsll((long long)todo) - 1;
-                    todo &= todo - 1;
-                    bwd_outside_coop<R>(ip, wb, ab, bb, gb_, gwn, goyn, goxn, g, rowy[j], tx0 + b);
+            // taps that left the tile: recomputed through clamped global gathers, overwriting
+            // what the hot loop stored for them (same lane or same wave: program order)
+            const bool flag = !(mabs[j] < (float)(R + 1));
+            unsigned long long todo = __ballot(flag && tx0 + (int)threadIdx.x == x);
+            if (todo) {  // wave-uniform, rare
+                float *gwn = gw ? gw + nb : nullptr, *goyn = goy ? goy + nb : nullptr,
+                      *goxn = gox ? gox + nb : nullptr;
+                if (__popcll(todo) <= kCoopMaxPixels) {
+                    while (todo) {
+                        const int b = __ffsll((long long)todo) - 1;
+                        todo &= todo - 1;
+                        const float sc = HEAD ? __shfl(occv[j], b) : 1.f;
+                        const float c = bwd_outside_coop<R>(ip, wb, ab, bb, gb_, gwn, goyn, goxn, g,
+                                                            rowy[j], tx0 + b, sc, HEAD);
+                        if (HEAD && x == tx0 + b) gocc[j] += c;
+                    }
+                } else if (flag) {
+                    const float c = bwd_outside_lane<R>(ip, wb, ab, bb, d[j][0], d[j][1], d[j][2], gwn,
+                                                        goyn, goxn, g, rowy[j],
+                                                        HEAD ? in_branch(x) : x,
+                                                        HEAD ? occv[j] : 1.f);
+                    if (HEAD) gocc[j] += c;
                 }
-            } else if (flag) {
-                bwd_outside_lane<R>(ip, wb, ab, bb, d[j][0], d[j][1], d[j][2], gwn, goyn, goxn, g,
-                                    rowy[j], x);
+            }
+            if constexpr (HEAD) {
+                if (ha.gocc)
+                    st_stream(ha.gocc + ((size_t)n * T + f) * pl + rf[j] + (unsigned)x, gocc[j]);
             }
         }
     }
@@ -1190,9 +1328,9 @@ void launch_fwd_tiled(const float *in, const float *w, const float *oy, const fl
                       const Geom &g, hipStream_t st)
 {
     typedef TileCfg<R> T;
-    hipLaunchKernelGGL((synth_fwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC>),
+    hipLaunchKernelGGL((synth_fwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false>),
                        pixel_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, in, w, oy, ox, out,
-                       g);
+                       g, HeadArgs{});
 }
 
 template <int R>
@@ -1202,13 +1340,38 @@ void launch_bwd_tiled(const float *in, const float *w, const float *oy, const fl
 {
     typedef TileCfg<R> T;
     if (gw && goy && gox)
-        hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true>),
+        hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true, false>),
                            pixel_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, in, w, oy, ox,
-                           gout, gw, goy, gox, g);
+                           gout, gw, goy, gox, g, HeadArgs{});
     else
-        hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false>),
+        hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false, false>),
                            pixel_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, in, w, oy, ox,
-                           gout, gw, goy, gox, g);
+                           gout, gw, goy, gox, g, HeadArgs{});
+}
+
+template <int R>
+void launch_head_fwd(const float *w, const float *oy, const float *ox, float *out, const Geom &g,
+                     const HeadArgs &ha, hipStream_t st)
+{
+    typedef TileCfg<R> T;
+    hipLaunchKernelGGL((synth_fwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true>),
+                       pixel_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, nullptr, w, oy, ox,
+                       out, g, ha);
+}
+
+template <int R>
+void launch_head_bwd(const float *w, const float *oy, const float *ox, const float *gout, float *gw,
+                     float *goy, float *gox, const Geom &g, const HeadArgs &ha, hipStream_t st)
+{
+    typedef TileCfg<R> T;
+    if (gw && goy && gox)
+        hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true, true>),
+                           pixel_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, nullptr, w, oy,
+                           ox, gout, gw, goy, gox, g, ha);
+    else
+        hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false, true>),
+                           pixel_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, nullptr, w, oy,
+                           ox, gout, gw, goy, gox, g, ha);
 }
 
 template <int KS>
@@ -1459,6 +1622,83 @@ int artemis_synth_backward_ex(const float *input, const float *weight, const flo
     return run_backward(g, rc, input, weight, offset_y, offset_x, grad_output, grad_input,
                         grad_weight, grad_offset_y, grad_offset_x, gin_mode, tile_radius, workspace,
                         workspace_bytes, stream);
+}
+
+// ---- fused ChronoSynth head ----------------------------------------------------------------
+static int head_setup(Geom &g, HeadArgs &ha, const char *what, const float *const *frames, int T,
+                      const float *occlusion, int B, int H, int W, int in_H, int in_W, int org_y,
+                      int org_x, int tile_radius, int &R)
+{
+    if (T < 1 || T > kMaxFrames)
+        return fail(hipErrorInvalidValue, "%s: T=%d context frames (1..%d supported)", what, T,
+                    kMaxFrames);
+    const int rc = make_geom_ex(g, B, 3, H, W, 5, 1, in_H, in_W, org_y, org_x);
+    if (rc != 0) return rc;
+    if ((long long)B * T > 65535LL * 64)
+        return fail(hipErrorInvalidValue, "%s: B*T too large", what);
+    if (!frames || !occlusion) return fail(hipErrorInvalidValue, "%s: NULL tensor pointer", what);
+    ha = HeadArgs{};
+    for (int f = 0; f < T; ++f) {
+        if (!frames[f]) return fail(hipErrorInvalidValue, "%s: frames[%d] is NULL", what, f);
+        ha.frame[f] = frames[f];
+    }
+    ha.occ = occlusion;
+    ha.T = T;
+    R = pick_radius(tile_radius);
+    if (R == 0) R = pick_radius(ARTEMIS_SYNTH_RADIUS_DEFAULT);  // the head has no direct variant
+    return 0;
+}
+
+int artemis_synth_head_forward(const float *const *frames, int T, const float *weights,
+                               const float *offsets_y, const float *offsets_x,
+                               const float *occlusion, float *output, int B, int H, int W, int in_H,
+                               int in_W, int org_y, int org_x, int tile_radius, void *stream)
+{
+    Geom g;
+    HeadArgs ha;
+    int R = 0;
+    const int rc = head_setup(g, ha, "artemis_synth_head_forward", frames, T, occlusion, B, H, W, in_H,
+                              in_W, org_y, org_x, tile_radius, R);
+    if (rc > 0) return rc;
+    if (rc < 0) return 0;
+    if (!weights || !offsets_y || !offsets_x || !output)
+        return fail(hipErrorInvalidValue, "artemis_synth_head_forward: NULL tensor pointer");
+    hipStream_t st = (hipStream_t)stream;
+    switch (R) {
+    case 2: launch_head_fwd<2>(weights, offsets_y, offsets_x, output, g, ha, st); break;
+    case 4: launch_head_fwd<4>(weights, offsets_y, offsets_x, output, g, ha, st); break;
+    case 8: launch_head_fwd<8>(weights, offsets_y, offsets_x, output, g, ha, st); break;
+    default: launch_head_fwd<16>(weights, offsets_y, offsets_x, output, g, ha, st); break;
+    }
+    return check_launch("artemis_synth_head_forward");
+}
+
+int artemis_synth_head_backward(const float *const *frames, int T, const float *weights,
+                                const float *offsets_y, const float *offsets_x,
+                                const float *occlusion, const float *grad_output,
+                                float *grad_weights, float *grad_offsets_y, float *grad_offsets_x,
+                                float *grad_occlusion, int B, int H, int W, int in_H, int in_W,
+                                int org_y, int org_x, int tile_radius, void *stream)
+{
+    Geom g;
+    HeadArgs ha;
+    int R = 0;
+    const int rc = head_setup(g, ha, "artemis_synth_head_backward", frames, T, occlusion, B, H, W,
+                              in_H, in_W, org_y, org_x, tile_radius, R);
+    if (rc > 0) return rc;
+    if (rc < 0) return 0;
+    if (!weights || !offsets_y || !offsets_x || !grad_output)
+        return fail(hipErrorInvalidValue, "artemis_synth_head_backward: NULL tensor pointer");
+    if (!grad_weights && !grad_offsets_y && !grad_offsets_x && !grad_occlusion) return 0;
+    ha.gocc = grad_occlusion;
+    hipStream_t st = (hipStream_t)stream;
+    switch (R) {
+    case 2: launch_head_bwd<2>(weights, offsets_y, offsets_x, grad_output, grad_weights, grad_offsets_y, grad_offsets_x, g, ha, st); break;
+    case 4: launch_head_bwd<4>(weights, offsets_y, offsets_x, grad_output, grad_weights, grad_offsets_y, grad_offsets_x, g, ha, st); break;
+    case 8: launch_head_bwd<8>(weights, offsets_y, offsets_x, grad_output, grad_weights, grad_offsets_y, grad_offsets_x, g, ha, st); break;
+    default: launch_head_bwd<16>(weights, offsets_y, offsets_x, grad_output, grad_weights, grad_offsets_y, grad_offsets_x, g, ha, st); break;
+    }
+    return check_launch("artemis_synth_head_backward");
 }
 
 int artemis_synth_offset_radius(const float *offset_y, const float *offset_x, size_t count,

@@ -25,6 +25,7 @@ Deliberate differences from the reference, all supersets:
 from __future__ import annotations
 
 import contextlib
+import ctypes
 import math
 from dataclasses import dataclass
 
@@ -230,6 +231,90 @@ def synth_strip(frame, weight, offset_y, offset_x, row0, dilation=1, padded=True
 def synth(input, weight, offset_y, offset_x, dilation=1):
     """Functional form of ``FunctionSynth.apply``."""
     return FunctionSynth.apply(input, weight, offset_y, offset_x, dilation)
+
+
+class FunctionChronoHead(torch.autograd.Function):
+    """``framet`` of ``ChronoSynth.forward`` (model/chrono_synth.py:114-129) as one fused op::
+
+        framet = sum_i occlusion[:, i:i+1] * FunctionSynth(ReplicationPad2d(frames[i]),
+                     weights[:, i], alphas[:, i], betas[:, i], dilation)
+
+    ``apply(weights, alphas, betas, occlusion, padded, *frames)``: weights/alphas/betas are the
+    (B, T, 25, H, W) tensors the sub-networks produce (``.view(B, T, -1, H, W)``, :109-111), read
+    in place; occlusion is (B, T, H, W) (:112); frames are T tensors (B, 3, H, W), or replication-
+    padded (B, 3, H+4, W+4) with ``padded=True``.  Gradients flow to weights, alphas, betas and
+    occlusion; frames get none (they are inputs in ArTEMIS).  Only k = 5, dilation = 1."""
+
+    @staticmethod
+    def forward(context, weights, alphas, betas, occlusion, padded, *frames):
+        T = len(frames)
+        if weights.dim() != 5 or weights.shape != alphas.shape or weights.shape != betas.shape:
+            raise ValueError("weights, alphas, betas must be (B, T, 25, H, W) of one shape")
+        B, Tw, K, H, W = weights.shape
+        if Tw != T:
+            raise ValueError(f"{T} frames but weights.size(1) = {Tw}")
+        if K != 25:
+            raise NotImplementedError("the fused head is built for kernel_size 5, dilation 1 "
+                                      "(config.py:26-27); compose FunctionSynth for other sizes")
+        if tuple(occlusion.shape) != (B, T, H, W):
+            raise ValueError("occlusion must be (B, T, H, W)")
+        pad = 2 if padded else 0
+        for t in (weights, alphas, betas, occlusion, *frames):
+            if t.dtype != torch.float32:
+                raise TypeError("the fused head is float32 only")
+            if t.device != weights.device:
+                raise ValueError("all operands must be on one device")
+            assert (t.is_contiguous() == True)
+        for f in frames:
+            if tuple(f.shape) != (B, 3, H + 2 * pad, W + 2 * pad):
+                raise ValueError(f"frame shape {tuple(f.shape)} does not match the head")
+            if f.requires_grad:
+                raise NotImplementedError("the fused head produces no frame gradients; use "
+                                          "FunctionSynthFrame per frame if they are needed")
+        if not weights.is_cuda:
+            raise NotImplementedError()
+
+        context.save_for_backward(weights, alphas, betas, occlusion, *frames)
+        context.geom = (B, T, H, W, H + 2 * pad, W + 2 * pad, pad - 2)
+        lib = _lib.load()
+        with torch.cuda.device(weights.device):
+            out = weights.new_empty(B, 3, H, W)
+            ptrs = (ctypes.c_void_p * T)(*[f.data_ptr() for f in frames])
+            _lib.check(lib.artemis_synth_head_forward(
+                ptrs, T, _ptr(weights), _ptr(alphas), _ptr(betas), _ptr(occlusion), _ptr(out),
+                B, H, W, H + 2 * pad, W + 2 * pad, pad - 2, pad - 2, int(options.tile_radius),
+                torch.cuda.current_stream().cuda_stream), "artemis_synth_head_forward")
+        return out
+
+    @staticmethod
+    def backward(context, gradOutput):
+        weights, alphas, betas, occlusion, *frames = context.saved_tensors
+        B, T, H, W, Hin, Win, org = context.geom
+        assert (gradOutput.is_contiguous() == True)
+        if gradOutput.dtype != torch.float32 or tuple(gradOutput.shape) != (B, 3, H, W):
+            raise ValueError("gradOutput must be float32 of the forward output's shape")
+        need = context.needs_input_grad
+        lib = _lib.load()
+        with torch.cuda.device(weights.device):
+            gw = torch.empty_like(weights) if need[0] else None
+            ga = torch.empty_like(alphas) if need[1] else None
+            gb = torch.empty_like(betas) if need[2] else None
+            gocc = torch.empty_like(occlusion) if need[3] else None
+            if any(need[:4]):
+                ptrs = (ctypes.c_void_p * T)(*[f.data_ptr() for f in frames])
+                _lib.check(lib.artemis_synth_head_backward(
+                    ptrs, T, _ptr(weights), _ptr(alphas), _ptr(betas), _ptr(occlusion),
+                    _ptr(gradOutput), _ptr(gw), _ptr(ga), _ptr(gb), _ptr(gocc), B, H, W, Hin, Win,
+                    org, org, int(options.tile_radius),
+                    torch.cuda.current_stream().cuda_stream), "artemis_synth_head_backward")
+        return (gw, ga, gb, gocc, None) + (None,) * T
+
+
+def chrono_head(frames, weights, alphas, betas, occlusion, dilation=1, padded=False):
+    """Drop-in for the loop at model/chrono_synth.py:114-129."""
+    if int(dilation) != 1:
+        raise NotImplementedError("the fused head is built for dilation 1 (config.py:27)")
+    return FunctionChronoHead.apply(weights, alphas, betas, occlusion, bool(padded), *frames)
 
 
 def offset_radius(offset_y, offset_x) -> torch.Tensor:

@@ -124,6 +124,42 @@ int artemis_synth_backward_ex(const float *input, const float *weight, const flo
 size_t artemis_synth_backward_workspace_bytes_ex(int N, int C, int H, int W, int k, int d, int in_H,
                                                  int in_W, int gin_mode);
 
+/* ---- fused ChronoSynth head --------------------------------------------------------------
+ * One call for what the reference's only caller does around the op for one pyramid level,
+ * model/chrono_synth.py:114-129:
+ *     for i in range(T):  warp_i = occlusion[:, i:i+1] *
+ *                                  FunctionSynth(ReplicationPad2d(frame_i), weights[:, i].contiguous(),
+ *                                                alphas[:, i].contiguous(), betas[:, i].contiguous(), d)
+ *     framet = sum(warp)
+ * The 5-D tensors are read in place (no .contiguous() copies: 600 B/pixel/frame of memcpy in the
+ * reference), the per-frame results never leave registers, and the output has the bits of the
+ * composition (product rounded to fp32, then added in frame order).
+ *   frames      HOST array of T device pointers, each (B, 3, in_H, in_W) fp32; geometry as in the
+ *               *_ex entry points (unpadded frames: in_H = H, in_W = W, org = -2; padded: in_H = H+4,
+ *               org = 0).  1 <= T <= 8.  The array is read during the call only.
+ *   weights / offsets_y / offsets_x   (B, T, 25, H, W) contiguous
+ *   occlusion   (B, T, H, W) contiguous          output  (B, 3, H, W)
+ * Only the model's configuration k = 5, d = 1, C = 3 (config.py:26-27) is built; tile_radius as
+ * above except that RADIUS_NONE means the default (the head has no direct-gather variant). */
+int artemis_synth_head_forward(const float *const *frames, int T, const float *weights,
+                               const float *offsets_y, const float *offsets_x,
+                               const float *occlusion, float *output, int B, int H, int W, int in_H,
+                               int in_W, int org_y, int org_x, int tile_radius, void *stream);
+
+/* Backward of artemis_synth_head_forward w.r.t. weights, offsets and occlusion (what autograd
+ * derives for model/chrono_synth.py:114-129 through FunctionSynth.backward, :316-391, the `occ *`
+ * product and the sum).  grad_output is (B, 3, H, W); grad_weights / grad_offsets_y /
+ * grad_offsets_x are (B, T, 25, H, W), grad_occlusion is (B, T, H, W); each may be NULL, the
+ * others are fully overwritten.  Frame gradients are not produced here (ArTEMIS's frames are
+ * inputs); a caller that needs them uses artemis_synth_backward_ex per frame with
+ * grad_output * occlusion. */
+int artemis_synth_head_backward(const float *const *frames, int T, const float *weights,
+                                const float *offsets_y, const float *offsets_x,
+                                const float *occlusion, const float *grad_output,
+                                float *grad_weights, float *grad_offsets_y, float *grad_offsets_x,
+                                float *grad_occlusion, int B, int H, int W, int in_H, int in_W,
+                                int org_y, int org_x, int tile_radius, void *stream);
+
 /* max over both offset tensors of |trunc(offset)| as one int32 written to *out_radius (device
  * memory), enqueued on `stream`: the tile_radius that would serve every tap from LDS.  `count`
  * = elements per tensor.  Helper for callers that want to size tile_radius; no reference

@@ -251,3 +251,51 @@ def forward_torch(input, weight, offset_y, offset_x, dilation=1):
                 + gather(top, right) * a * b
             )
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# The ChronoSynth head around the op: model/chrono_synth.py:114-129 restated with numpy around
+# the C oracle (fp32, the reference's operation order: pad, op, `occ *`, Python `sum`).
+
+def head_forward(frames, weights, alphas, betas, occlusion, dilation=1):
+    """``framet`` of ChronoSynth.forward for operands already at output size:
+    frames: T arrays (B, C, H, W) unpadded; weights/alphas/betas (B, T, k*k, H, W);
+    occlusion (B, T, H, W).  Returns (framet, [S_i]) with S_i the per-frame op outputs."""
+    weights, alphas, betas, occlusion = map(_f32, (weights, alphas, betas, occlusion))
+    T = weights.shape[1]
+    k = int(math.sqrt(weights.shape[2]))
+    p = int(((k - 1) * dilation) / 2.0)                       # kernel_pad, :60
+    warp, synth = [], []
+    for i in range(T):                                        # :115
+        frame = _f32(frames[i])
+        padded = np.pad(frame, ((0, 0), (0, 0), (p, p), (p, p)), mode="edge")   # modulePad, :63,125
+        s_i = forward(padded, weights[:, i], alphas[:, i], betas[:, i], dilation)   # :125-126
+        synth.append(s_i)
+        warp.append(occlusion[:, i:i + 1] * s_i)              # :123-124 (fp32 product)
+    framet = warp[0]
+    for wpi in warp[1:]:                                      # sum(warp), :129: left to right
+        framet = framet + wpi
+    return framet.astype(np.float32), synth
+
+
+def head_backward(grad_out, frames, weights, alphas, betas, occlusion, dilation=1):
+    """Gradients of ``head_forward``'s framet w.r.t. (weights, alphas, betas, occlusion) as
+    autograd derives them: d(sum) passes grad_out to every warp_i; d(occ * S): gS = occ * g,
+    gocc = sum_c g * S; then FunctionSynth.backward (cupy_module/synth.py:316-391) per frame."""
+    grad_out, weights, alphas, betas, occlusion = map(
+        _f32, (grad_out, weights, alphas, betas, occlusion))
+    T = weights.shape[1]
+    k = int(math.sqrt(weights.shape[2]))
+    p = int(((k - 1) * dilation) / 2.0)
+    gw, ga, gb = (np.zeros_like(weights) for _ in range(3))
+    gocc = np.zeros_like(occlusion)
+    for i in range(T):
+        padded = np.pad(_f32(frames[i]), ((0, 0), (0, 0), (p, p), (p, p)), mode="edge")
+        w_i, a_i, b_i = (np.ascontiguousarray(t[:, i]) for t in (weights, alphas, betas))
+        s_i = forward(padded, w_i, a_i, b_i, dilation)
+        gs = (occlusion[:, i:i + 1] * grad_out).astype(np.float32)
+        gocc[:, i] = (grad_out.astype(np.float64) * s_i).sum(1)
+        gw[:, i] = grad_weight(gs, padded, w_i, a_i, b_i, dilation)
+        ga[:, i] = grad_alpha(gs, padded, w_i, a_i, b_i, dilation)
+        gb[:, i] = grad_beta(gs, padded, w_i, a_i, b_i, dilation)
+    return gw, ga, gb, gocc
