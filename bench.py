@@ -91,6 +91,73 @@ def cpu_baseline(threads, sigma):
     }
 
 
+def head_timing(device, radius, sigma, iters=20):
+    """Beside the headline: the whole ChronoSynth head (model/chrono_synth.py:114-129: pad, 4 x op,
+    occlusion product, sum; forward + backward to weights/alphas/betas/occlusion) at 1080p,
+    (a) as the fused artemis_synth_head_* pair through the C ABI and (b) as the reference's own
+    composition around this library's per-frame op with torch doing the rest (batch 1 and batch 2:
+    from batch 2 on the reference's `.contiguous()` slices are real copies)."""
+    import artemis_amd
+    lib = _lib.load()
+    stream = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device=device)
+    g.manual_seed(7)
+    res = {}
+    for B in (1, 2):
+        T = FRAMES
+        frames = [torch.rand(B, C, H, W, device=device, generator=g) for _ in range(T)]
+        w = torch.softmax(torch.randn(B, T, K_TAPS, H, W, device=device, generator=g), 2)
+        a = torch.randn(B, T, K_TAPS, H, W, device=device, generator=g) * sigma
+        b = torch.randn(B, T, K_TAPS, H, W, device=device, generator=g) * sigma
+        occ = torch.softmax(torch.randn(B, T, H, W, device=device, generator=g), 1)
+        gout = torch.randn(B, C, H, W, device=device, generator=g)
+        out = torch.empty(B, C, H, W, device=device)
+        gw, ga, gb = (torch.empty_like(w) for _ in range(3))
+        gocc = torch.empty_like(occ)
+        import ctypes
+        ptrs = (ctypes.c_void_p * T)(*[f.data_ptr() for f in frames])
+
+        def fused():
+            _lib.check(lib.artemis_synth_head_forward(
+                ptrs, T, w.data_ptr(), a.data_ptr(), b.data_ptr(), occ.data_ptr(), out.data_ptr(),
+                B, H, W, H, W, -2, -2, radius, stream), "head_forward")
+            _lib.check(lib.artemis_synth_head_backward(
+                ptrs, T, w.data_ptr(), a.data_ptr(), b.data_ptr(), occ.data_ptr(), gout.data_ptr(),
+                gw.data_ptr(), ga.data_ptr(), gb.data_ptr(), gocc.data_ptr(), B, H, W, H, W, -2, -2,
+                radius, stream), "head_backward")
+
+        leaves = [t.clone().requires_grad_(True) for t in (w, a, b, occ)]
+
+        def composed():
+            lw, la, lb, locc = leaves
+            warp = []
+            with artemis_amd.synth_options(tile_radius=radius):
+                for i in range(T):
+                    padded = torch.nn.functional.pad(frames[i], (PAD,) * 4, mode="replicate")
+                    warp.append(locc[:, i:i + 1] * artemis_amd.FunctionSynth.apply(
+                        padded, lw[:, i].contiguous(), la[:, i].contiguous(),
+                        lb[:, i].contiguous(), 1))
+                sum(warp).backward(gout)
+            for t in leaves:
+                t.grad = None
+
+        for name, fn in (("fused", fused), ("composed", composed)):
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / iters
+            res[f"{name}_b{B}_ms"] = round(ms, 4)
+            res[f"{name}_b{B}_Mpix_s"] = round(B * H * W / (ms * 1e-3) / 1e6, 1)
+        del leaves, frames, w, a, b, occ, gw, ga, gb
+        torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,6 +170,7 @@ def main():
                          "(library default 16 is 2-3 %% slower here and robust to sigma = 4)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, host cpus)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-head", action="store_true", help="skip the fused-head side measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -233,6 +301,8 @@ def main():
                 "avg_launch_ms": round(bwd_ms, 4),
             },
         }
+        if world == 1 and not args.no_head:
+            line["config"]["chrono_head_fwd_bwd_1080p"] = head_timing(device, args.radius, args.sigma)
         if not args.no_cpu_baseline:
             threads = args.cpu_threads or min(16, os.cpu_count() or 1)
             line["cpu_baseline"] = cpu_baseline(threads, args.sigma)

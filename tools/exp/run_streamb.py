@@ -9,7 +9,7 @@ dev = torch.device("cuda:0")
 H, W = 1080, 1920
 sets = [[torch.randn(1, 25, H, W, device=dev) for _ in range(6)] for _ in range(3)]
 st = torch.cuda.current_stream().cuda_stream
-variants = [16, 43, 50, 51, 52, 53, 57, 58, 46, 54, 55, 56]
+variants = [int(v) for v in sys.argv[1].split(',')] if len(sys.argv) > 1 else [47, 67, 60, 61, 64, 65, 66, 46, 62, 63]
 T = {v: [] for v in variants}
 for rnd in range(9):
     for v in variants:
@@ -20,5 +20,5 @@ for rnd in range(9):
         if rnd: T[v].append(e0.elapsed_time(e1))
 for v in variants:
     med = statistics.median(T[v])
-    nb = 312.0 if v in (35,36,37,38,39,44,45,46,54,55,56) else 600.0
+    nb = 312.0 if v in (35,36,37,38,39,44,45,46,54,55,56,62,63) else 600.0
     print(f"stream variant {v:2d}: {med*1e3:8.1f} us (min {min(T[v])*1e3:8.1f}) {nb*H*W/med/1e6:7.0f} GB/s")

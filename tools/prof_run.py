@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--sigma", type=float, default=1.0)
     ap.add_argument("--radius", type=int, default=-1)
     ap.add_argument("--gin", type=int, default=-1, help="-1 none, 0 atomic, 1 deterministic")
+    ap.add_argument("--head", action="store_true", help="also run the fused ChronoSynth head pair")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.load()
@@ -47,6 +48,27 @@ def main():
                 f["gw"].data_ptr(), f["ga"].data_ptr(), f["gb"].data_ptr(), 1, 3, H, W, 5, 1,
                 max(a.gin, 0), a.radius, ws.data_ptr() if ws is not None else None, wsb, st),
                 "bwd")
+    if a.head:
+        import ctypes
+        T = 4
+        ptrs = (ctypes.c_void_p * T)(*[f["inp"].data_ptr() for f in frames])
+        g = torch.Generator(device=dev).manual_seed(5)
+        w = torch.softmax(torch.randn(1, T, 25, H, W, device=dev, generator=g), 2)
+        al = torch.randn(1, T, 25, H, W, device=dev, generator=g) * a.sigma
+        be = torch.randn(1, T, 25, H, W, device=dev, generator=g) * a.sigma
+        occ = torch.softmax(torch.randn(1, T, H, W, device=dev, generator=g), 1)
+        gw, ga, gb = (torch.empty_like(w) for _ in range(3))
+        gocc = torch.empty_like(occ)
+        out = frames[0]["out"]
+        gout = frames[0]["gout"]
+        for _ in range(a.iters):
+            _lib.check(lib.artemis_synth_head_forward(
+                ptrs, T, w.data_ptr(), al.data_ptr(), be.data_ptr(), occ.data_ptr(), out.data_ptr(),
+                1, H, W, H + 4, W + 4, 0, 0, a.radius, st), "head fwd")
+            _lib.check(lib.artemis_synth_head_backward(
+                ptrs, T, w.data_ptr(), al.data_ptr(), be.data_ptr(), occ.data_ptr(), gout.data_ptr(),
+                gw.data_ptr(), ga.data_ptr(), gb.data_ptr(), gocc.data_ptr(), 1, H, W, H + 4, W + 4,
+                0, 0, a.radius, st), "head bwd")
     torch.cuda.synchronize()
 
 
