@@ -243,7 +243,9 @@ class FunctionChronoHead(torch.autograd.Function):
     (B, T, 25, H, W) tensors the sub-networks produce (``.view(B, T, -1, H, W)``, :109-111), read
     in place; occlusion is (B, T, H, W) (:112); frames are T tensors (B, 3, H, W), or replication-
     padded (B, 3, H+4, W+4) with ``padded=True``.  Gradients flow to weights, alphas, betas and
-    occlusion; frames get none (they are inputs in ArTEMIS).  Only k = 5, dilation = 1."""
+    occlusion from the fused backward kernel; a frame that requires grad (none does in ArTEMIS)
+    gets the op's gradInput for ``gradOutput * occlusion[:, i]`` through the per-frame entry point.
+    Only k = 5, dilation = 1."""
 
     @staticmethod
     def forward(context, weights, alphas, betas, occlusion, padded, *frames):
@@ -268,9 +270,6 @@ class FunctionChronoHead(torch.autograd.Function):
         for f in frames:
             if tuple(f.shape) != (B, 3, H + 2 * pad, W + 2 * pad):
                 raise ValueError(f"frame shape {tuple(f.shape)} does not match the head")
-            if f.requires_grad:
-                raise NotImplementedError("the fused head produces no frame gradients; use "
-                                          "FunctionSynthFrame per frame if they are needed")
         if not weights.is_cuda:
             raise NotImplementedError()
 
@@ -307,7 +306,18 @@ class FunctionChronoHead(torch.autograd.Function):
                     _ptr(gradOutput), _ptr(gw), _ptr(ga), _ptr(gb), _ptr(gocc), B, H, W, Hin, Win,
                     org, org, int(options.tile_radius),
                     torch.cuda.current_stream().cuda_stream), "artemis_synth_head_backward")
-        return (gw, ga, gb, gocc, None) + (None,) * T
+            # Frame gradients (ArTEMIS never asks for them: its frames are inputs) are not part of
+            # the fused kernel: per frame, gradInput of the op for gradOutput * occ_f.
+            gframes = [None] * T
+            for f in range(T):
+                if not need[5 + f]:
+                    continue
+                gs = (occlusion[:, f:f + 1] * gradOutput).contiguous()
+                gframes[f] = _launch_backward(
+                    (True, False, False, False), gs, frames[f], weights[:, f].contiguous(),
+                    alphas[:, f].contiguous(), betas[:, f].contiguous(), 1,
+                    (B, 3, H, W, 5, Hin, Win, org, org))[0]
+        return (gw, ga, gb, gocc, None, *gframes)
 
 
 def chrono_head(frames, weights, alphas, betas, occlusion, dilation=1, padded=False):

@@ -150,7 +150,7 @@ int artemis_synth_head_forward(const float *const *frames, int T, const float *w
  * derives for model/chrono_synth.py:114-129 through FunctionSynth.backward, :316-391, the `occ *`
  * product and the sum).  grad_output is (B, 3, H, W); grad_weights / grad_offsets_y /
  * grad_offsets_x are (B, T, 25, H, W), grad_occlusion is (B, T, H, W); each may be NULL, the
- * others are fully overwritten.  Frame gradients are not produced here (ArTEMIS's frames are
+ * others are fully overwritten.  Frame gradients are not part of this kernel (ArTEMIS's frames are
  * inputs); a caller that needs them uses artemis_synth_backward_ex per frame with
  * grad_output * occlusion. */
 int artemis_synth_head_backward(const float *const *frames, int T, const float *weights,

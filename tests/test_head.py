@@ -227,3 +227,26 @@ def test_head_full_size_equals_composition(dev):
         scale = float(x.grad.abs().max())
         err = float((f - x.grad).abs().max())
         assert err <= BWD_RTOL * scale, (name, err, scale)
+
+
+@pytest.mark.gpu
+def test_head_frame_gradients_through_the_per_frame_entry_point(dev, oracle):
+    # north_star: "gradients for the input, the kernels, the offsets and the mask".  Frames that
+    # require grad get the op's gradInput for gradOutput * occ_f (oracle: its fp64 adjoint).
+    import artemis_amd
+    frames, w, a, b, occ, gout = head_operands(2, 3, 21, 70, "gauss1", seed=31)
+    tf = [torch.from_numpy(f).to(dev).requires_grad_(i != 1) for i, f in enumerate(frames)]
+    t = [torch.from_numpy(x).to(dev).requires_grad_(True) for x in (w, a, b, occ)]
+    out = artemis_amd.chrono_head(tf, *t)
+    out.backward(torch.from_numpy(gout).to(dev))
+    torch.cuda.synchronize()
+    assert tf[1].grad is None
+    for i in (0, 2):
+        gs = (occ[:, i:i + 1] * gout).astype(np.float32)
+        ref = oracle.backward_ex(gs, frames[i], np.ascontiguousarray(w[:, i]),
+                                 np.ascontiguousarray(a[:, i]), np.ascontiguousarray(b[:, i]), 1,
+                                 origin=(-2, -2))[0]
+        close(tf[i].grad, ref, BWD_RTOL, f"grad frame {i}")
+    rgw, rga, rgb, rgocc = oracle.head_backward(gout, frames, w, a, b, occ, 1)
+    close(t[0].grad, rgw, BWD_RTOL)
+    close(t[3].grad, rgocc, BWD_RTOL)
