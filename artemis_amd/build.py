@@ -6,16 +6,20 @@ import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
-SRC = os.path.join(_PKG, "csrc", "synth_kernels.hip")
+CSRC = os.path.join(_PKG, "csrc")
+SRC = os.path.join(CSRC, "synth_kernels.hip")        # C ABI, host logic, direct kernels
+TILES_SRC = os.path.join(CSRC, "synth_tiles.hip")     # LDS-staged kernels, one object per radius
+DEVICE_HDR = os.path.join(CSRC, "synth_device.hpp")
+TILE_RADII = (2, 4, 8, 16)
 INCLUDE = os.path.join(_ROOT, "include")
 LIB_DIR = os.path.join(_PKG, "lib")
+OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB_PATH = os.path.join(LIB_DIR, "libartemis_synth.so")
 
 HIPCC_FLAGS = [
     "--offload-arch=gfx950",
     "-O3",
     "-fPIC",
-    "-shared",
     "-munsafe-fp-atomics",  # fp32 atomicAdd -> one global_atomic_add_f32, no CAS loop
     # contract a*b+c only where one source expression spells it (not wherever the backend finds
     # a chance): every unrolled copy of the per-row arithmetic then rounds identically, so a pixel's
@@ -29,22 +33,37 @@ def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [SRC, os.path.join(INCLUDE, "artemis_synth.h")]
+    deps = [SRC, TILES_SRC, DEVICE_HDR, os.path.join(INCLUDE, "artemis_synth.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile the HIP kernels + C ABI into artemis_amd/lib/libartemis_synth.so."""
+def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
+    """Compile the HIP kernels + C ABI into artemis_amd/lib/libartemis_synth.so: the host
+    translation unit and one object per tile radius in parallel, then one link."""
     if not force and not needs_build():
         return LIB_PATH
-    os.makedirs(LIB_DIR, exist_ok=True)
+    os.makedirs(OBJ_DIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "hipcc")
-    cmd = [hipcc, *HIPCC_FLAGS, "-I" + INCLUDE, "-o", LIB_PATH, SRC]
+    jobs = [(SRC, os.path.join(OBJ_DIR, "synth_kernels.o"), [])]
+    jobs += [(TILES_SRC, os.path.join(OBJ_DIR, f"synth_tiles_r{r}.o"), [f"-DSYNTH_TILE_R={r}"])
+             for r in TILE_RADII]
+    procs = []
+    for src, obj, defs in jobs:
+        cmd = [hipcc, *HIPCC_FLAGS, *extra_flags, *defs, "-I" + INCLUDE, "-c", "-o", obj, src]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                            text=True)))
+    for cmd, pr in procs:
+        _, err = pr.communicate()
+        if pr.returncode != 0:
+            raise RuntimeError("hipcc failed: " + " ".join(cmd) + "\n" + err)
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + [j[1] for j in jobs]
     if verbose:
-        print(" ".join(cmd))
-    r = subprocess.run(cmd, capture_output=True, text=True)
+        print(" ".join(link))
+    r = subprocess.run(link, capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + r.stderr)
+        raise RuntimeError("link failed:\n" + r.stderr)
     return LIB_PATH
 
 

@@ -1,0 +1,1266 @@
+// synth_device.hpp -- device code of the ArTEMIS frame-synthesis op for MI355X (gfx950, CDNA4).
+//
+// What it computes (reference: /root/reference/cupy_module/synth.py, kernel text :6-201):
+//   out[n,c,y,x] = sum_{r,s<k} w[n,rk+s,y,x] * B(in[n,c], y+r*d+trunc(a), x+s*d+trunc(b),
+//                                                a-trunc(a), b-trunc(b))
+//   a = offset_y[n,rk+s,y,x], b = offset_x[...], trunc = C (int) cast, B = 2x2 blend with the
+//   four indices clamped to the padded frame.  Backward: gradWeight, gradOffset_y,
+//   gradOffset_x as in the reference's three kernels, fused; gradInput (absent upstream) as the
+//   exact adjoint.
+//
+// Design (DESIGN.md has the numbers): the op is an HBM stream of the 3 x 25 per-pixel planes
+// (300 of 324 B/pixel forward, 600 of 624 B/pixel backward) with a 4-corner x 3-channel gather
+// from a 12 B/pixel frame.  One lane owns one output pixel (64 lanes = 64 consecutive x, so every
+// plane access of a wave is one coalesced 256 B segment) and keeps all channels in registers,
+// so the planes are read once (the reference re-reads them per channel).  The frame tile of a
+// 64 x TH pixel workgroup, extended by the tap footprint and a displacement radius R, is staged
+// once into LDS as float4 {c0,c1,c2,-} texels with the border clamp already applied, so the
+// gathers are ds_read_b128 from one address register with immediate offsets and never touch
+// the vector memory pipe.  Taps displaced beyond R fall back per lane to clamped global loads.
+// No MFMA: there is no dense contraction here.
+#ifndef ARTEMIS_SYNTH_DEVICE_HPP
+#define ARTEMIS_SYNTH_DEVICE_HPP
+// Included by synth_kernels.hip (C ABI, host logic, direct kernels) and by synth_tiles.hip, which
+// is compiled once per LDS tile radius (-DSYNTH_TILE_R=2|4|8|16) so the heavy unrolled kernels
+// build in parallel.  Everything but the few types and launcher declarations that cross
+// translation units lives in an anonymous namespace.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "artemis_synth.h"
+
+namespace asynth {
+
+// Problem geometry shared by all kernels. Frame row index of tap (r) at output row y with
+// truncated offset ia is  y + oy0 + r*d + ia  (oy0 = ox0 = 0 for the reference layout).
+struct Geom {
+    int N, C, H, W;
+    int k, d;
+    int Hin, Win;
+    int oy0, ox0;
+};
+
+constexpr int kMaxFrames = 8;
+
+// arguments of the fused ChronoSynth head kernels (ignored by the single-frame instantiations)
+struct HeadArgs {
+    const float *frame[kMaxFrames];  // T frames, each (N, 3, Hin, Win)
+    const float *occ;                // (N, T, H, W)
+    float *gocc;                     // backward only: (N, T, H, W) or null
+    int T;
+};
+
+// Launchers of the LDS-staged kernels, one explicit instantiation per radius in synth_tiles.hip.
+template <int R>
+void launch_fwd_tiled(const float *in, const float *w, const float *oy, const float *ox, float *out,
+                      const Geom &g, hipStream_t st);
+template <int R>
+void launch_bwd_tiled(const float *in, const float *w, const float *oy, const float *ox,
+                      const float *gout, float *gw, float *goy, float *gox, const Geom &g,
+                      hipStream_t st);
+template <int R>
+void launch_head_fwd(const float *w, const float *oy, const float *ox, float *out, const Geom &g,
+                     const HeadArgs &ha, hipStream_t st);
+template <int R>
+void launch_head_bwd(const float *w, const float *oy, const float *ox, const float *gout, float *gw,
+                     float *goy, float *gox, const Geom &g, const HeadArgs &ha, hipStream_t st);
+template <int R, bool FIXED>
+void launch_gin_tiled(const float *w, const float *oy, const float *ox, const float *gout, float *gin,
+                      unsigned char *ws, const Geom &g, int bits, hipStream_t st);
+
+inline dim3 pixel_grid(const Geom &g, int rows_per_block)
+{
+    return dim3((unsigned)((g.W + 63) / 64), (unsigned)((g.H + rows_per_block - 1) / rows_per_block),
+                (unsigned)g.N);
+}
+
+}  // namespace asynth
+
+namespace {
+
+using asynth::Geom;
+using asynth::HeadArgs;
+using asynth::kMaxFrames;
+using asynth::pixel_grid;
+
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
+
+// two's-complement wrapping add, as the device's integer add in the reference does
+__device__ __forceinline__ int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
+
+// ------------------------------------------------------------------------------------------
+// Direct path: any k, d, C.  Gathers go through L1/L2.  One lane per (n, y, x).
+// Block (64,4): a wave is 64 consecutive x of one row.  The per-pixel bodies are also the
+// fix-up path of the LDS-staged kernels below.
+// ------------------------------------------------------------------------------------------
+
+struct TapIdx {
+    int bl, tl, br, tr;  // element offsets inside one frame plane
+    float fa, fb;
+};
+
+__device__ __forceinline__ TapIdx tap_index(const Geom &g, float a, float b, int ybase, int xbase)
+{
+    TapIdx t;
+    const int ia = (int)a, ib = (int)b;  // v_cvt_i32_f32: toward zero, saturating, NaN -> 0
+    const int yy = wadd(ybase, ia), xx = wadd(xbase, ib);
+    const int bottom = clampi(yy, 0, g.Hin - 1), top = clampi(wadd(yy, 1), 0, g.Hin - 1);
+    const int left = clampi(xx, 0, g.Win - 1), right = clampi(wadd(xx, 1), 0, g.Win - 1);
+    t.bl = bottom * g.Win + left;
+    t.tl = top * g.Win + left;
+    t.br = bottom * g.Win + right;
+    t.tr = top * g.Win + right;
+    t.fa = a - (float)ia;
+    t.fb = b - (float)ib;
+    return t;
+}
+
+// Forward for one pixel, channels [c0, c0 + CH).  wp/ap/bp point at tap 0 of this pixel,
+// ip at channel c0 of this sample's frame, op at channel c0 of this pixel's output.
+// KS > 0 fixes the filter size at compile time: a tap row's loads and gathers are then issued
+// together (the LDS kernels' fix-up runs this with one or two lanes active, so only the length of
+// the dependent-latency chain matters: 2 round trips per tap row instead of 2 per tap).
+template <int CH, int KS = 0>
+__device__ __forceinline__ void fwd_pixel_direct(const float *__restrict__ ip,
+                                                 const float *__restrict__ wp,
+                                                 const float *__restrict__ ap,
+                                                 const float *__restrict__ bp,
+                                                 float *__restrict__ op, const Geom &g, int y, int x)
+{
+    const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
+    const int k = KS > 0 ? KS : g.k;
+    float acc[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) acc[c] = 0.f;
+#pragma unroll 1
+    for (int r = 0; r < k; ++r) {
+#pragma unroll
+        for (int s = 0; s < k; ++s) {
+            const size_t t = (size_t)(r * k + s) * plane;
+            const float wv = wp[t], a = ap[t], b = bp[t];
+            const TapIdx ti = tap_index(g, a, b, y + g.oy0 + r * g.d, x + g.ox0 + s * g.d);
+            const float ga = 1.f - ti.fa, gb = 1.f - ti.fb;
+            const float c00 = ga * gb, c10 = ti.fa * gb, c01 = ga * ti.fb, c11 = ti.fa * ti.fb;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const float *p = ip + (size_t)c * iplane;
+                acc[c] += wv * (p[ti.bl] * c00 + p[ti.tl] * c10 + p[ti.br] * c01 + p[ti.tr] * c11);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) op[(size_t)c * plane] = acc[c];
+}
+
+template <int CH, int KS>
+__global__ __launch_bounds__(256) void synth_fwd_direct(const float *__restrict__ in,
+                                                         const float *__restrict__ w,
+                                                         const float *__restrict__ oy,
+                                                         const float *__restrict__ ox,
+                                                         float *__restrict__ out, Geom g, int c0)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    const int n = blockIdx.z;
+    if (x >= g.W || y >= g.H) return;
+    const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
+    const size_t pix = (size_t)y * g.W + x;
+    const size_t tb = (size_t)n * g.k * g.k * plane + pix;
+    fwd_pixel_direct<CH, KS>(in + ((size_t)n * g.C + c0) * iplane, w + tb, oy + tb, ox + tb,
+                         out + ((size_t)n * g.C + c0) * plane + pix, g, y, x);
+}
+
+// Fused gradWeight / gradOffset_y / gradOffset_x for one pixel, all C channels (run-time loop
+// unless CH > 0).  gwp/goyp/goxp point at tap 0 of this pixel (each may be null), gp at channel 0
+// of gradOutput.  KS as in fwd_pixel_direct.
+template <int CH = 0, int KS = 0>
+__device__ __forceinline__ void bwd_pixel_direct(const float *__restrict__ ip,
+                                                 const float *__restrict__ wp,
+                                                 const float *__restrict__ ap,
+                                                 const float *__restrict__ bp,
+                                                 const float *__restrict__ gp,
+                                                 float *__restrict__ gwp, float *__restrict__ goyp,
+                                                 float *__restrict__ goxp, const Geom &g, int y,
+                                                 int x)
+{
+    const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
+    const int k = KS > 0 ? KS : g.k;
+    const int C = CH > 0 ? CH : g.C;
+#pragma unroll 1
+    for (int r = 0; r < k; ++r) {
+#pragma unroll
+        for (int s = 0; s < k; ++s) {
+            const size_t t = (size_t)(r * k + s) * plane;
+            const float a = ap[t], b = bp[t];
+            const TapIdx ti = tap_index(g, a, b, y + g.oy0 + r * g.d, x + g.ox0 + s * g.d);
+            // channel-reduced corner sums: P_q = sum_c delta_c * corner_q(c)
+            float pbl = 0.f, ptl = 0.f, pbr = 0.f, ptr_ = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float dl = gp[(size_t)c * plane];
+                const float *p = ip + (size_t)c * iplane;
+                pbl += dl * p[ti.bl];
+                ptl += dl * p[ti.tl];
+                pbr += dl * p[ti.br];
+                ptr_ += dl * p[ti.tr];
+            }
+            const float fa = ti.fa, fb = ti.fb;
+            const float dlt = ptl - pbl, drt = ptr_ - pbr;
+            const float lft = pbl + fa * dlt, rgt = pbr + fa * drt, across = rgt - lft;
+            if (gwp) gwp[t] = lft + fb * across;
+            if (goyp || goxp) {
+                const float wv = wp[t];
+                if (goyp) goyp[t] = wv * (dlt + fb * (drt - dlt));
+                if (goxp) goxp[t] = wv * across;
+            }
+        }
+    }
+}
+
+template <int CH, int KS>
+__global__ __launch_bounds__(256) void synth_bwd_direct(const float *__restrict__ in,
+                                                         const float *__restrict__ w,
+                                                         const float *__restrict__ oy,
+                                                         const float *__restrict__ ox,
+                                                         const float *__restrict__ gout,
+                                                         float *__restrict__ gw,
+                                                         float *__restrict__ goy,
+                                                         float *__restrict__ gox, Geom g)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    const int n = blockIdx.z;
+    if (x >= g.W || y >= g.H) return;
+    const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
+    const size_t pix = (size_t)y * g.W + x;
+    const size_t tb = (size_t)n * g.k * g.k * plane + pix;
+    bwd_pixel_direct<CH, KS>(in + (size_t)n * g.C * iplane, w + tb, oy + tb, ox + tb,
+                     gout + (size_t)n * g.C * plane + pix, gw ? gw + tb : nullptr,
+                     goy ? goy + tb : nullptr, gox ? gox + tb : nullptr, g, y, x);
+}
+
+// gradInput, fp32 atomics straight to global memory (any k, d, C).  gin must be zeroed.
+template <int CH, int KS>
+__global__ __launch_bounds__(256) void synth_gin_atomic_direct(const float *__restrict__ w,
+                                                                const float *__restrict__ oy,
+                                                                const float *__restrict__ ox,
+                                                                const float *__restrict__ gout,
+                                                                float *__restrict__ gin, Geom g)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    const int n = blockIdx.z;
+    if (x >= g.W || y >= g.H) return;
+    const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
+    const int k = KS > 0 ? KS : g.k, C = CH > 0 ? CH : g.C;
+    const size_t pix = (size_t)y * g.W + x;
+    const size_t tbase = (size_t)n * k * k * plane + pix;
+    float *op = gin + (size_t)n * C * iplane;
+    const float *gp = gout + (size_t)n * C * plane + pix;
+#pragma unroll 1
+    for (int r = 0; r < k; ++r) {
+#pragma unroll
+        for (int s = 0; s < k; ++s) {
+            const size_t t = tbase + (size_t)(r * k + s) * plane;
+            const float wv = w[t], a = oy[t], b = ox[t];
+            const TapIdx ti = tap_index(g, a, b, y + g.oy0 + r * g.d, x + g.ox0 + s * g.d);
+            const float ga = 1.f - ti.fa, gb = 1.f - ti.fb;
+            const float c00 = ga * gb, c10 = ti.fa * gb, c01 = ga * ti.fb, c11 = ti.fa * ti.fb;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float dw = gp[(size_t)c * plane] * wv;
+                float *p = op + (size_t)c * iplane;
+                atomicAdd(p + ti.bl, dw * c00);
+                atomicAdd(p + ti.tl, dw * c10);
+                atomicAdd(p + ti.br, dw * c01);
+                atomicAdd(p + ti.tr, dw * c11);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Deterministic gradInput: every contribution is rounded to a 64-bit fixed-point integer with
+// one scale for the whole call and added with integer atomics.  Integer addition is
+// associative, so the sums (and the fp32 result) are bit-identical run to run whatever the
+// arrival order, for any offsets.  The scale 2^S is chosen from max|w| * max|gradOutput| so
+// that the worst case (every tap of a plane clamped onto one texel) cannot overflow.
+// Workspace: [0] max|w| bits, [1] max|gout| bits (uint32, atomicMax on non-negative float
+// bits), accumulators (int64, one per gradInput element) from byte 256.
+// ------------------------------------------------------------------------------------------
+
+constexpr size_t kDetHeaderBytes = 256;
+
+__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ v, size_t count,
+                                                      unsigned *__restrict__ slot)
+{
+    unsigned m = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned bits = __float_as_uint(v[i]) & 0x7fffffffu;
+        m = max(m, bits);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(slot, m);
+}
+
+// log2 of the fixed-point scale; a pure function of the two maxima, identical in every lane.
+// Every contribution  gradOut * w * coef  is bounded by m = 4 max|w| max|gradOut| < 2^e
+// (|coef| < 4: (1 + |fa|)(1 + |fb|) with |fa|, |fb| < 1), so scaled by 2^(30 - e) it rounds to an
+// int32 (one v_rndne + v_cvt; its 24-bit mantissa is all the precision the fp32 product has) and
+// is added, sign-extended, into a 64-bit integer.  count_bits bounds how many contributions can
+// meet in one element so that even that sum stays below 2^62.
+__device__ __forceinline__ int det_scale_log2(const unsigned *hdr, int count_bits)
+{
+    const float mw = __uint_as_float(hdr[0]), mg = __uint_as_float(hdr[1]);
+    float m = 4.f * mw * mg;
+    if (!(m > 0.f) || !(m < 3.0e38f)) return 0;
+    int e;
+    frexpf(m, &e);  // m < 2^e
+    return min(30, 62 - count_bits) - e;
+}
+
+__device__ __forceinline__ unsigned long long to_fixed(float contrib_scaled)
+{
+    return (unsigned long long)(long long)(int)rintf(contrib_scaled);  // saturating, NaN -> 0
+}
+
+template <int CH, int KS>
+__global__ __launch_bounds__(256) void synth_gin_fixed_direct(const float *__restrict__ w,
+                                                               const float *__restrict__ oy,
+                                                               const float *__restrict__ ox,
+                                                               const float *__restrict__ gout,
+                                                               unsigned char *__restrict__ ws,
+                                                               Geom g, int count_bits)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    const int n = blockIdx.z;
+    if (x >= g.W || y >= g.H) return;
+    const float scale = ldexpf(1.f, det_scale_log2((const unsigned *)ws, count_bits));
+    unsigned long long *accum = (unsigned long long *)(ws + kDetHeaderBytes);
+    const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
+    const int k = KS > 0 ? KS : g.k, C = CH > 0 ? CH : g.C;
+    const size_t pix = (size_t)y * g.W + x;
+    const size_t tbase = (size_t)n * k * k * plane + pix;
+    unsigned long long *op = accum + (size_t)n * C * iplane;
+    const float *gp = gout + (size_t)n * C * plane + pix;
+#pragma unroll 1
+    for (int r = 0; r < k; ++r) {
+#pragma unroll
+        for (int s = 0; s < k; ++s) {
+            const size_t t = tbase + (size_t)(r * k + s) * plane;
+            const float wv = w[t], a = oy[t], b = ox[t];
+            const TapIdx ti = tap_index(g, a, b, y + g.oy0 + r * g.d, x + g.ox0 + s * g.d);
+            const float ga = 1.f - ti.fa, gb = 1.f - ti.fb;
+            const float c00 = ga * gb, c10 = ti.fa * gb, c01 = ga * ti.fb, c11 = ti.fa * ti.fb;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float dw = gp[(size_t)c * plane] * wv * scale;
+                unsigned long long *p = op + (size_t)c * iplane;
+                atomicAdd(p + ti.bl, to_fixed(dw * c00));
+                atomicAdd(p + ti.tl, to_fixed(dw * c10));
+                atomicAdd(p + ti.br, to_fixed(dw * c01));
+                atomicAdd(p + ti.tr, to_fixed(dw * c11));
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void det_finalize_kernel(const unsigned char *__restrict__ ws,
+                                                            float *__restrict__ gin, size_t count,
+                                                            int count_bits)
+{
+    const double inv = ldexp(1.0, -det_scale_log2((const unsigned *)ws, count_bits));  // exact
+    const long long *accum = (const long long *)(ws + kDetHeaderBytes);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+         i += (size_t)gridDim.x * blockDim.x)
+        gin[i] = (float)((double)accum[i] * inv);
+}
+
+// ------------------------------------------------------------------------------------------
+// LDS-staged kernels for k = 5, d = 1, C = 3 (the model's configuration).
+// Workgroup = WAVES waves as (64, WAVES): tile of 64 x TH output pixels, TH = WAVES * ROWS; wave w
+// owns rows w, w + WAVES, ...
+// LDS tile: (TH + 5 + 2R) x (64 + 5 + 2R) float4 texels, texel (ly, lx) = the three channels of
+// frame pixel (clamp(gy0 + ly), clamp(gx0 + lx)): the reference's CLAMP is applied at fill
+// time, so reading (ly, ly+1) x (lx, lx+1) needs no clamp.  A tap is served from LDS when
+// 0 <= ly <= LH-2 and 0 <= lx <= LW-2, i.e. |trunc(offset)| <= R.
+// ------------------------------------------------------------------------------------------
+
+constexpr int kTW = 64;
+
+// Native 4-float vector and its LDS-qualified form.  Tile reads go through an explicit
+// address_space(3) pointer: with a generic pointer hipcc merges the LDS read and the global
+// fallback into one flat_load per dword (select of pointers), which kills the design.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+
+// compile-time loop: the body receives std::integral_constant-like tags so that the tap index
+// can be a template argument (immediate LDS offsets)
+template <int V>
+struct IntTag {
+    static constexpr int value = V;
+};
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (B < E) {
+        f(IntTag<B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+template <int R, int TH>
+struct TileShape {
+    static constexpr int LW = kTW + 5 + 2 * R;
+    static constexpr int LH = TH + 5 + 2 * R;
+};
+
+// The 75 weight/offset planes and the gradient planes are touched exactly once per launch:
+// non-temporal accesses keep them from displacing the (re-read) frame in L2 and, measured on
+// MI355X, lift a mixed read/write stream from ~4.9 to ~6.3 TB/s (tools/exp/exp_bw.hip).
+#ifndef SYNTH_NT
+#define SYNTH_NT 1
+#endif
+__device__ __forceinline__ float ld_stream(const float *p)
+{
+#if SYNTH_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void st_stream(float *p, float v)
+{
+#if SYNTH_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
+// ------------------------------------------------------------------------------------------
+// Fix-up of taps that leave the staged tile (k = 5, d = 1, C = 3).  The hot loops give such a
+// tap weight 0 (forward) or let its stores be overwritten (backward); afterwards only those taps
+// are recomputed through clamped global gathers, so the cost grows with the number of far taps,
+// not with 25 x the number of pixels that have one.  When few pixels of a wave are affected
+// (a few dozen per 1080p frame at sigma = 1) the whole wave handles one pixel at a time, lane
+// l < 25 owning tap l: two memory round trips per pixel.  A lane walking its taps alone pays
+// up to 50 dependent round trips at the very end of its workgroup, and a launch cannot end before
+// its slowest workgroup: measured, that tail cost 8 us (forward) to 50 us (backward) per launch.
+// All 64 lanes must be active (the tap-major kernels never retire single lanes).
+// ------------------------------------------------------------------------------------------
+
+constexpr int kCoopMaxPixels = 12;  // more flagged lanes than this: every lane fixes its own pixel
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+struct Float3 {
+    float x, y, z;
+};
+
+// A tap is served from the staged tile iff both of its offsets satisfy |offset| < R + 1.  The
+// hot loops and the fix-ups below use this one predicate, so every tap is computed exactly once.
+template <int R>
+__device__ __forceinline__ bool tap_in_tile(float a, float b)
+{
+    return fmaxf(fabsf(a), fabsf(b)) < (float)(R + 1);
+}
+
+// Contribution of ONE tap (clamped global gathers), channels 0..2.
+__device__ __forceinline__ Float3 fwd_tap_global(const float *__restrict__ ip, const Geom &g, float wv,
+                                                 float a, float b, int yb, int xb)
+{
+    const size_t iplane = (size_t)g.Hin * g.Win;
+    const TapIdx ti = tap_index(g, a, b, yb, xb);
+    const float ga = 1.f - ti.fa, gb = 1.f - ti.fb;
+    const float c00 = ga * gb, c10 = ti.fa * gb, c01 = ga * ti.fb, c11 = ti.fa * ti.fb;
+    const float *p0 = ip, *p1 = ip + iplane, *p2 = ip + 2 * iplane;
+    Float3 o;
+    o.x = wv * (p0[ti.bl] * c00 + p0[ti.tl] * c10 + p0[ti.br] * c01 + p0[ti.tr] * c11);
+    o.y = wv * (p1[ti.bl] * c00 + p1[ti.tl] * c10 + p1[ti.br] * c01 + p1[ti.tr] * c11);
+    o.z = wv * (p2[ti.bl] * c00 + p2[ti.tl] * c10 + p2[ti.br] * c01 + p2[ti.tr] * c11);
+    return o;
+}
+
+// Sum over the out-of-tile taps of pixel (y, xs), computed by the whole wave (lane l < 25 owns
+// tap l).  wb/ab/bb: tap 0 of the sample's planes; ip: the sample's frame.  Result in every lane.
+template <int R>
+__device__ __forceinline__ Float3 fwd_outside_coop(const float *__restrict__ ip,
+                                                   const float *__restrict__ wb,
+                                                   const float *__restrict__ ab,
+                                                   const float *__restrict__ bb, const Geom &g, int y,
+                                                   int xs)
+{
+    const int l = threadIdx.x & 63;
+    const size_t plane = (size_t)g.H * g.W;
+    Float3 c = {0.f, 0.f, 0.f};
+    if (l < 25) {
+        const size_t o = (size_t)l * plane + (size_t)y * g.W + xs;
+        const float a = ab[o], b = bb[o];
+        if (!tap_in_tile<R>(a, b)) {
+            const int r = l / 5, s = l - 5 * r;
+            c = fwd_tap_global(ip, g, wb[o], a, b, y + g.oy0 + r, xs + g.ox0 + s);
+        }
+    }
+    c.x = wave_sum(c.x);
+    c.y = wave_sum(c.y);
+    c.z = wave_sum(c.z);
+    return c;
+}
+
+// The same sum by one lane for its own pixel (used when many lanes of the wave are flagged).
+template <int R>
+__device__ __forceinline__ Float3 fwd_outside_lane(const float *__restrict__ ip,
+                                                   const float *__restrict__ wp,
+                                                   const float *__restrict__ ap,
+                                                   const float *__restrict__ bp, const Geom &g, int y,
+                                                   int x)
+{
+    const size_t plane = (size_t)g.H * g.W;
+    Float3 c = {0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int r = 0; r < 5; ++r) {
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            const size_t o = (size_t)(r * 5 + s) * plane;
+            const float a = ap[o], b = bp[o];
+            if (!tap_in_tile<R>(a, b)) {
+                const Float3 t = fwd_tap_global(ip, g, wp[o], a, b, y + g.oy0 + r, x + g.ox0 + s);
+                c.x += t.x;
+                c.y += t.y;
+                c.z += t.z;
+            }
+        }
+    }
+    return c;
+}
+
+// One tap of the fused backward through clamped global gathers; o = element offset of
+// (tap, y, x) in the sample's 25-plane tensors.  The three gradients are stored times `scale`
+// (the occlusion weight in the fused head, 1 otherwise); returns w * (unscaled gradWeight), the
+// tap's share of the occlusion gradient.
+__device__ __forceinline__ float bwd_tap_global(const float *__restrict__ ip, const Geom &g, float wv,
+                                                float a, float b, float d0, float d1, float d2, int yb,
+                                                int xb, float *__restrict__ gwn,
+                                                float *__restrict__ goyn, float *__restrict__ goxn,
+                                                size_t o, float scale)
+{
+    const size_t iplane = (size_t)g.Hin * g.Win;
+    const TapIdx ti = tap_index(g, a, b, yb, xb);
+    const float *p0 = ip, *p1 = ip + iplane, *p2 = ip + 2 * iplane;
+    const float pbl = d0 * p0[ti.bl] + d1 * p1[ti.bl] + d2 * p2[ti.bl];
+    const float ptl = d0 * p0[ti.tl] + d1 * p1[ti.tl] + d2 * p2[ti.tl];
+    const float pbr = d0 * p0[ti.br] + d1 * p1[ti.br] + d2 * p2[ti.br];
+    const float ptr_ = d0 * p0[ti.tr] + d1 * p1[ti.tr] + d2 * p2[ti.tr];
+    const float dlt = ptl - pbl, drt = ptr_ - pbr;
+    const float lft = pbl + ti.fa * dlt, rgt = pbr + ti.fa * drt, across = rgt - lft;
+    const float gwr = lft + ti.fb * across;
+    const float gar = wv * (dlt + ti.fb * (drt - dlt));
+    const float gbr = wv * across;
+    if (gwn) gwn[o] = scale * gwr;
+    if (goyn) goyn[o] = scale * gar;
+    if (goxn) goxn[o] = scale * gbr;
+    return wv * gwr;
+}
+
+// Out-of-tile taps of pixel (y, xs) recomputed and stored by the whole wave.
+// gn: the sample's gradOutput planes; gwn/goyn/goxn: tap 0 of the sample's gradient planes.
+// Returns (in every lane) the sum over those taps of w * unscaled gradWeight.
+template <int R>
+__device__ __forceinline__ float bwd_outside_coop(const float *__restrict__ ip,
+                                                  const float *__restrict__ wb,
+                                                  const float *__restrict__ ab,
+                                                  const float *__restrict__ bb,
+                                                  const float *__restrict__ gn, float *__restrict__ gwn,
+                                                  float *__restrict__ goyn, float *__restrict__ goxn,
+                                                  const Geom &g, int y, int xs, float scale,
+                                                  bool want_sum)
+{
+    const int l = threadIdx.x & 63;
+    float c = 0.f;
+    if (l < 25) {
+        const size_t plane = (size_t)g.H * g.W;
+        const size_t pix = (size_t)y * g.W + xs;
+        const size_t o = (size_t)l * plane + pix;
+        const float a = ab[o], b = bb[o];
+        if (!tap_in_tile<R>(a, b)) {
+            const int r = l / 5, s = l - 5 * r;
+            c = bwd_tap_global(ip, g, wb[o], a, b, gn[pix], gn[plane + pix], gn[2 * plane + pix],
+                               y + g.oy0 + r, xs + g.ox0 + s, gwn, goyn, goxn, o, scale);
+        }
+    }
+    return want_sum ? wave_sum(c) : 0.f;
+}
+
+template <int R>
+__device__ __forceinline__ float bwd_outside_lane(const float *__restrict__ ip,
+                                                  const float *__restrict__ wb,
+                                                  const float *__restrict__ ab,
+                                                  const float *__restrict__ bb, float d0, float d1,
+                                                  float d2, float *__restrict__ gwn,
+                                                  float *__restrict__ goyn, float *__restrict__ goxn,
+                                                  const Geom &g, int y, int x, float scale)
+{
+    const size_t plane = (size_t)g.H * g.W;
+    const size_t pix = (size_t)y * g.W + x;
+    float c = 0.f;
+#pragma unroll 1
+    for (int r = 0; r < 5; ++r) {
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            const size_t o = (size_t)(r * 5 + s) * plane + pix;
+            const float a = ab[o], b = bb[o];
+            if (!tap_in_tile<R>(a, b))
+                c += bwd_tap_global(ip, g, wb[o], a, b, d0, d1, d2, y + g.oy0 + r, x + g.ox0 + s, gwn,
+                                    goyn, goxn, o, scale);
+        }
+    }
+    return c;
+}
+
+// ------------------------------------------------------------------------------------------
+// Tap-major variants.  Same tile, same per-tap arithmetic, different loop order: a wave owns
+// ROWS pixel rows (tile = 64 x 4*ROWS) and walks the 25 taps in the OUTER loop, visiting its
+// rows inside each tap.  All workgroups of a residency round start together and advance through
+// the taps at about the same pace, so chip-wide only a few of the 75 (forward) / 150 (backward)
+// planes are being streamed at any moment and each plane is swept almost linearly.  HBM3E
+// needs that: measured on MI355X (tools/exp), 150 concurrent plane streams run at ~5.1 TB/s,
+// a handful at ~6.4-6.6 TB/s, because a DRAM row that is opened for 256 B costs as much as
+// one that delivers 1 KB.
+// ------------------------------------------------------------------------------------------
+
+#ifndef SYNTH_ROWGROUP
+#define SYNTH_ROWGROUP 4
+#endif
+constexpr int kRowGroup = SYNTH_ROWGROUP;  // rows whose LDS gathers may be in flight together
+
+template <int ROWS>
+struct TapCol {
+    float w[ROWS], a[ROWS], b[ROWS];
+};
+
+// wbase/abase/bbase: wave-uniform pointers to tap 0 of this sample; roff[j]: uniform element
+// offsets of the wave's rows.  Uniform base + 32-bit lane offset -> saddr addressing.
+template <int ROWS>
+__device__ __forceinline__ void load_tap_col(TapCol<ROWS> &t, const float *__restrict__ wbase,
+                                             const float *__restrict__ abase,
+                                             const float *__restrict__ bbase, size_t plane, int tap,
+                                             const size_t (&roff)[ROWS], unsigned x)
+{
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+        const size_t o = (size_t)tap * plane + roff[j];
+        t.w[j] = ld_stream(wbase + o + x);
+        t.a[j] = ld_stream(abase + o + x);
+        t.b[j] = ld_stream(bbase + o + x);
+    }
+}
+
+// Stage the clamped frame tile.  Texels are fetched in batches of kFillBatch per lane with all of
+// a batch's loads issued before the first LDS write: left to itself hipcc waits vmcnt(0) after
+// every texel, which serialises ~14 L2 round trips (~10 us) at the head of every workgroup.
+constexpr int kFillBatch = 7;
+
+template <int R, int TH, int THREADS>
+__device__ __forceinline__ void fill_tile_n(f32x4 *tile, const float *__restrict__ ip, const Geom &g,
+                                            int gy0, int gx0, int tid)
+{
+    constexpr int LW = TileShape<R, TH>::LW, LH = TileShape<R, TH>::LH;
+    constexpr int N = LH * LW;
+    const int iplane = g.Hin * g.Win;
+#pragma unroll 1
+    for (int base = tid; base < N; base += THREADS * kFillBatch) {
+        float c0[kFillBatch], c1[kFillBatch], c2[kFillBatch];
+#pragma unroll
+        for (int u = 0; u < kFillBatch; ++u) {
+            const int i = min(base + u * THREADS, N - 1);  // tail lanes re-fetch the last texel
+            const int ly = i / LW, lx = i - ly * LW;
+            const int gy = clampi(gy0 + ly, 0, g.Hin - 1), gx = clampi(gx0 + lx, 0, g.Win - 1);
+            const int o = gy * g.Win + gx;
+            c0[u] = ip[o];
+            c1[u] = ip[(size_t)iplane + o];
+            c2[u] = ip[2 * (size_t)iplane + o];
+        }
+#pragma unroll
+        for (int u = 0; u < kFillBatch; ++u) {
+            const int i = min(base + u * THREADS, N - 1);
+            tile[i] = f32x4{c0[u], c1[u], c2[u], 0.f};
+        }
+    }
+}
+
+struct Corners {
+    f32x4 bl, tl, br, tr;
+};
+
+// Byte address (within the tile) of the bottom-left texel of a tap's footprint:
+//   ((py + r + R + ia) * LW + (px + s + R + ib)) * 16
+//       = ia * (LW*16) + ib * 16 + rowbase + TAPOFF*16
+// rowbase = ((py + R) * LW + px + R) * 16 is one VGPR per row, set up once; the tap's own
+// displacement TAPOFF = r * LW + s is a compile-time constant that rides in the ds_read
+// immediate offset, so a tap costs v_mad_i32_i24 + v_lshl_add_u32 + v_min_u32.
+// The unsigned min keeps the four reads in bounds whatever the offsets are (a negative address
+// is a huge unsigned); a tap that really is outside is caught by the |offset| test below.
+template <int R, int TH, int TAPOFF>
+__device__ __forceinline__ Corners tile_corners_at(const lds_f32x4 *tile, int ia, int ib,
+                                                   int rowbase)
+{
+    constexpr int LW = TileShape<R, TH>::LW, LH = TileShape<R, TH>::LH;
+    const unsigned addr = (unsigned)(__mul24(ia, LW * 16) + rowbase + (ib << 4));
+    const unsigned safe = min(addr, (unsigned)(((LH - 1) * LW - 2 - TAPOFF) * 16));
+    const lds_f32x4 *p =
+        (const lds_f32x4 *)((const __attribute__((address_space(3))) char *)tile + safe);
+    Corners q;
+    q.bl = p[TAPOFF];
+    q.br = p[TAPOFF + 1];
+    q.tl = p[TAPOFF + LW];
+    q.tr = p[TAPOFF + LW + 1];
+    return q;
+}
+
+// |offset| < R + 1  =>  |trunc(offset)| <= R  =>  the footprint of every tap of every row of the
+// tile lies inside the staged tile.  One v_max3_f32 (with |.| source modifiers) per tap keeps the
+// running maximum; the comparison is made once per pixel.  NaN offsets truncate to 0 and stay in
+// the tile, so max's NaN-ignoring behaviour is the right one; +-inf is caught.
+__device__ __forceinline__ float track_abs(float m, float a, float b)
+{
+    return fmaxf(m, fmaxf(fabsf(a), fabsf(b)));
+}
+
+// The fused ChronoSynth head (HEAD = true; model/chrono_synth.py:114-129) runs the same body once
+// per context frame inside the workgroup: frame f's tile is staged, its 25 taps are applied with
+// the weights/offsets of slice [n, f] of the 5-D tensors read in place, and the result is folded
+// into  out = sum_f occ[n, f] * S_f  in registers, in the reference's order (product rounded,
+// then added: `occ * moduleSynth(...)`, Python `sum`), so the output has the bits of the
+// composition without its intermediate tensors.
+
+// Inside the head's frame loop every per-tap address (tap * plane + row offset: 200 wave-uniform
+// 64-bit values) is loop-invariant, and LLVM hoists them all out of the loop and then spills
+// them.  Passing the two ingredients through an empty asm once per frame makes them opaque, so
+// the addresses are formed where they are used, as in the single-frame kernels.
+__device__ __forceinline__ size_t per_frame(size_t v)
+{
+    asm volatile("" : "+s"(v));
+    return v;
+}
+
+// ... and the rare fix-up's 25 per-tap addresses of each row (lane-dependent) are hoisted to the
+// top of the frame iteration and spilled across the hot loop unless the lane's column is made
+// opaque inside the fix-up branch.
+__device__ __forceinline__ int in_branch(int v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+
+template <int R, int WAVES, int ROWS, int OCC, bool HEAD>
+__global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
+    const float *__restrict__ in, const float *__restrict__ w, const float *__restrict__ oy,
+    const float *__restrict__ ox, float *__restrict__ out, Geom g, HeadArgs ha)
+{
+    constexpr int TH = WAVES * ROWS;
+    constexpr int LW = TileShape<R, TH>::LW, LH = TileShape<R, TH>::LH;
+    __shared__ f32x4 tile[LH * LW];
+    const lds_f32x4 *ltile = (const lds_f32x4 *)tile;
+    const int tx0 = blockIdx.x * kTW, ty0 = blockIdx.y * TH, n = blockIdx.z;
+    const int wy = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int tid = wy * 64 + threadIdx.x;
+    const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
+    // A lane past the right edge acts as the last image column (same operands, same arithmetic,
+    // same stores as that column's owner), like the rows below: no lane ever retires on its own,
+    // so wave-wide operations in the fix-up see all 64 lanes.
+    const int x = min(tx0 + (int)threadIdx.x, g.W - 1), px = x - tx0;
+    const bool active = ty0 + wy < g.H;  // wave-uniform
+
+    // A row past the bottom edge is replaced by the last image row: the wave then recomputes
+    // and re-stores exactly what that row's owner stores (same operands, same arithmetic), which
+    // keeps the unrolled body free of per-row branches.
+    int rowy[ROWS];
+    size_t roff[ROWS];
+    int rowbase[ROWS];
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+        rowy[j] = min(ty0 + wy + WAVES * j, g.H - 1);
+        roff[j] = (size_t)rowy[j] * g.W;
+        rowbase[j] = ((rowy[j] - ty0 + R) * LW + px + R) * 16;
+    }
+    float res0[ROWS], res1[ROWS], res2[ROWS];  // HEAD: the running sum over frames
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) res0[j] = res1[j] = res2[j] = 0.f;
+
+    const int T = HEAD ? ha.T : 1;
+    for (int f = 0; f < T; ++f) {
+        size_t pl = plane, rf[ROWS];
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) rf[j] = roff[j];
+        if constexpr (HEAD) {
+            pl = per_frame(pl);
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) rf[j] = per_frame(rf[j]);
+        }
+        const float *ip = (HEAD ? ha.frame[f] : in) + (size_t)n * 3 * iplane;
+        const size_t nb = ((size_t)n * T + f) * 25 * pl;
+        const float *wb = w + nb, *ab = oy + nb, *bb = ox + nb;
+
+        // first tap of this lane's pixels: issued before the tile fill so the stream is already
+        // in flight while the tile is staged
+        TapCol<ROWS> cur;
+        float occv[ROWS];
+        if (active) {
+            load_tap_col<ROWS>(cur, wb, ab, bb, pl, 0, rf, (unsigned)x);
+            if constexpr (HEAD) {
+                const float *op = ha.occ + ((size_t)n * T + f) * pl;
+#pragma unroll
+                for (int j = 0; j < ROWS; ++j) occv[j] = ld_stream(op + rf[j] + (unsigned)x);
+            }
+        }
+
+        if (HEAD && f > 0) __syncthreads();  // every wave is done with the previous frame's tile
+        fill_tile_n<R, TH, 64 * WAVES>(tile, ip, g, ty0 + g.oy0 - R, tx0 + g.ox0 - R, tid);
+        __syncthreads();
+        if (!active) {
+            if constexpr (HEAD) continue;  // keeps taking part in the fills and barriers
+            else return;
+        }
+
+        float acc0[ROWS], acc1[ROWS], acc2[ROWS];
+        float mabs[ROWS];
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {
+            acc0[j] = acc1[j] = acc2[j] = 0.f;
+            mabs[j] = 0.f;
+        }
+        static_for<0, 25>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            constexpr int r = t / 5, s = t % 5;
+            TapCol<ROWS> nxt;
+            if (t < 24) load_tap_col<ROWS>(nxt, wb, ab, bb, pl, t + 1, rf, (unsigned)x);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) {
+                float wv = cur.w[j];
+                const float a = cur.a[j], b = cur.b[j];
+                const int ia = (int)a, ib = (int)b;
+                const float fa = a - (float)ia, fb = b - (float)ib;
+                mabs[j] = track_abs(mabs[j], a, b);
+                const Corners q = tile_corners_at<R, TH, r * LW + s>(ltile, ia, ib, rowbase[j]);
+                const float ga = 1.f - fa, gb = 1.f - fb;
+                const float c00 = ga * gb, c10 = fa * gb, c01 = ga * fb, c11 = fa * fb;
+                wv = tap_in_tile<R>(a, b) ? wv : 0.f;  // a far tap is added by the fix-up instead
+                acc0[j] += wv * (q.bl.x * c00 + q.tl.x * c10 + q.br.x * c01 + q.tr.x * c11);
+                acc1[j] += wv * (q.bl.y * c00 + q.tl.y * c10 + q.br.y * c01 + q.tr.y * c11);
+                acc2[j] += wv * (q.bl.z * c00 + q.tl.z * c10 + q.br.z * c01 + q.tr.z * c11);
+                // Pin the arithmetic in place: instruction selection otherwise floats the
+                // chain-free FMAs to the end of the unrolled block, keeping every LDS result of
+                // the pixel live (512 VGPRs or spills).  The sched_barrier bounds the LDS results
+                // in flight to kRowGroup rows (16 VGPRs each).
+                asm volatile("" : "+v"(acc0[j]), "+v"(acc1[j]), "+v"(acc2[j]), "+v"(mabs[j]));
+                if (j % kRowGroup == kRowGroup - 1) __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
+        });
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {
+            // taps that left the tile are added through clamped global gathers
+            const bool flag = !(mabs[j] < (float)(R + 1));
+            unsigned long long todo = __ballot(flag && tx0 + (int)threadIdx.x == x);
+            if (todo) {  // wave-uniform, rare
+                if (__popcll(todo) <= kCoopMaxPixels) {
+                    while (todo) {
+                        const int b = __ffsll((long long)todo) - 1;
+                        todo &= todo - 1;
+                        const Float3 c = fwd_outside_coop<R>(ip, wb, ab, bb, g, rowy[j], tx0 + b);
+                        if (x == tx0 + b) {  // the owner and its right-edge duplicates
+                            acc0[j] += c.x;
+                            acc1[j] += c.y;
+                            acc2[j] += c.z;
+                        }
+                    }
+                } else if (flag) {
+                    const size_t o = rf[j] + x;
+                    const Float3 c = fwd_outside_lane<R>(ip, wb + o, ab + o, bb + o, g, rowy[j], x);
+                    acc0[j] += c.x;
+                    acc1[j] += c.y;
+                    acc2[j] += c.z;
+                }
+            }
+            if constexpr (HEAD) {
+                // occ * S_f rounded to fp32, then added: the reference's two separate ops
+                const float p0 = occv[j] * acc0[j], p1 = occv[j] * acc1[j], p2 = occv[j] * acc2[j];
+                res0[j] = res0[j] + p0;
+                res1[j] = res1[j] + p1;
+                res2[j] = res2[j] + p2;
+            } else {
+                res0[j] = acc0[j];
+                res1[j] = acc1[j];
+                res2[j] = acc2[j];
+            }
+        }
+    }
+    if (HEAD && !active) return;
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+        float *orow = out + (size_t)n * 3 * plane + roff[j];
+        st_stream(orow + (unsigned)x, res0[j]);
+        st_stream(orow + plane + (unsigned)x, res1[j]);
+        st_stream(orow + 2 * plane + (unsigned)x, res2[j]);
+    }
+}
+
+// HEAD = true: the fused ChronoSynth head's backward.  gradOutput is the gradient of
+// out = sum_f occ_f * S_f; per frame the kernel forms the unscaled tap gradients from it, stores
+// them times occ_f into slice [n, f] of the 5-D gradient tensors in place, and accumulates
+// gocc[n, f] = sum_c gradOutput_c * S_f,c = sum_t w_t * (unscaled gradWeight_t) in registers.
+template <int R, int WAVES, int ROWS, int OCC, bool ALL, bool HEAD>
+__global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
+    const float *__restrict__ in, const float *__restrict__ w, const float *__restrict__ oy,
+    const float *__restrict__ ox, const float *__restrict__ gout, float *__restrict__ gw,
+    float *__restrict__ goy, float *__restrict__ gox, Geom g, HeadArgs ha)
+{
+    constexpr int TH = WAVES * ROWS;
+    constexpr int LW = TileShape<R, TH>::LW, LH = TileShape<R, TH>::LH;
+    __shared__ f32x4 tile[LH * LW];
+    const lds_f32x4 *ltile = (const lds_f32x4 *)tile;
+    const int tx0 = blockIdx.x * kTW, ty0 = blockIdx.y * TH, n = blockIdx.z;
+    const int wy = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int tid = wy * 64 + threadIdx.x;
+    const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
+    // lanes past the right edge duplicate the last image column (see forward)
+    const int x = min(tx0 + (int)threadIdx.x, g.W - 1), px = x - tx0;
+    const bool active = ty0 + wy < g.H;  // wave-uniform
+
+    int rowy[ROWS];  // rows past the bottom edge duplicate the last image row (see forward)
+    size_t roff[ROWS];
+    int rowbase[ROWS];
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+        rowy[j] = min(ty0 + wy + WAVES * j, g.H - 1);
+        roff[j] = (size_t)rowy[j] * g.W;
+        rowbase[j] = ((rowy[j] - ty0 + R) * LW + px + R) * 16;
+    }
+    const float *gb_ = gout + (size_t)n * 3 * plane;
+    float d[ROWS][3];
+
+    const int T = HEAD ? ha.T : 1;
+    for (int f = 0; f < T; ++f) {
+        size_t pl = plane, rf[ROWS];
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) rf[j] = roff[j];
+        if constexpr (HEAD) {
+            pl = per_frame(pl);
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) rf[j] = per_frame(rf[j]);
+        }
+        const float *ip = (HEAD ? ha.frame[f] : in) + (size_t)n * 3 * iplane;
+        const size_t nb = ((size_t)n * T + f) * 25 * pl;
+        const float *wb = w + nb, *ab = oy + nb, *bb = ox + nb;
+
+        TapCol<ROWS> cur;
+        float occv[ROWS], gocc[ROWS];
+        if (active) {
+            load_tap_col<ROWS>(cur, wb, ab, bb, pl, 0, rf, (unsigned)x);
+            if constexpr (HEAD) {
+                const float *op = ha.occ + ((size_t)n * T + f) * pl;
+#pragma unroll
+                for (int j = 0; j < ROWS; ++j) {
+                    occv[j] = ld_stream(op + rf[j] + (unsigned)x);
+                    gocc[j] = 0.f;
+                }
+            }
+        }
+
+        if (HEAD && f > 0) __syncthreads();  // every wave is done with the previous frame's tile
+        fill_tile_n<R, TH, 64 * WAVES>(tile, ip, g, ty0 + g.oy0 - R, tx0 + g.ox0 - R, tid);
+        __syncthreads();
+        if (!active) {
+            if constexpr (HEAD) continue;
+            else return;
+        }
+
+        float mabs[ROWS];
+        if (f == 0) {  // gradOutput is the same for every frame of the head
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) {
+                d[j][0] = ld_stream(gb_ + rf[j] + (unsigned)x);
+                d[j][1] = ld_stream(gb_ + pl + rf[j] + (unsigned)x);
+                d[j][2] = ld_stream(gb_ + 2 * pl + rf[j] + (unsigned)x);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) mabs[j] = 0.f;
+        static_for<0, 25>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            constexpr int r = t / 5, s = t % 5;
+            TapCol<ROWS> nxt;
+            if (t < 24) load_tap_col<ROWS>(nxt, wb, ab, bb, pl, t + 1, rf, (unsigned)x);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) {
+                const float wv = cur.w[j], a = cur.a[j], b = cur.b[j];
+                const int ia = (int)a, ib = (int)b;
+                const float fa = a - (float)ia, fb = b - (float)ib;
+                mabs[j] = track_abs(mabs[j], a, b);
+                const Corners q = tile_corners_at<R, TH, r * LW + s>(ltile, ia, ib, rowbase[j]);
+                const float pbl = d[j][0] * q.bl.x + d[j][1] * q.bl.y + d[j][2] * q.bl.z;
+                const float ptl = d[j][0] * q.tl.x + d[j][1] * q.tl.y + d[j][2] * q.tl.z;
+                const float pbr = d[j][0] * q.br.x + d[j][1] * q.br.y + d[j][2] * q.br.z;
+                const float ptr_ = d[j][0] * q.tr.x + d[j][1] * q.tr.y + d[j][2] * q.tr.z;
+                const float dl = ptl - pbl, dr = ptr_ - pbr;
+                const float lft = pbl + fa * dl, rgt = pbr + fa * dr;
+                const float across = rgt - lft;
+                const size_t o = nb + (size_t)t * pl + rf[j];
+                if constexpr (HEAD) {
+                    const float gwr = lft + fb * across;
+                    const float gar = wv * (dl + fb * (dr - dl));
+                    const float gbr = wv * across;
+                    // a far tap's share comes from the fix-up, which also overwrites its stores
+                    gocc[j] += (tap_in_tile<R>(a, b) ? wv : 0.f) * gwr;
+                    if (ALL || gw) st_stream(gw + o + (unsigned)x, occv[j] * gwr);
+                    if (ALL || goy) st_stream(goy + o + (unsigned)x, occv[j] * gar);
+                    if (ALL || gox) st_stream(gox + o + (unsigned)x, occv[j] * gbr);
+                    asm volatile("" : "+v"(mabs[j]), "+v"(gocc[j]));
+                } else {
+                    if (ALL || gw) st_stream(gw + o + (unsigned)x, lft + fb * across);
+                    if (ALL || goy) st_stream(goy + o + (unsigned)x, wv * (dl + fb * (dr - dl)));
+                    if (ALL || gox) st_stream(gox + o + (unsigned)x, wv * across);
+                    asm volatile("" : "+v"(mabs[j]));
+                }
+                if (j % kRowGroup == kRowGroup - 1) __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
+        });
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {
+            // taps that left the tile: recomputed through clamped global gathers, overwriting
+            // what the hot loop stored for them (same lane or same wave: program order)
+            const bool flag = !(mabs[j] < (float)(R + 1));
+            unsigned long long todo = __ballot(flag && tx0 + (int)threadIdx.x == x);
+            if (todo) {  // wave-uniform, rare
+                float *gwn = gw ? gw + nb : nullptr, *goyn = goy ? goy + nb : nullptr,
+                      *goxn = gox ? gox + nb : nullptr;
+                if (__popcll(todo) <= kCoopMaxPixels) {
+                    while (todo) {
+                        const int b = __ffsll((long long)todo) - 1;
+                        todo &= todo - 1;
+                        const float sc = HEAD ? __shfl(occv[j], b) : 1.f;
+                        const float c = bwd_outside_coop<R>(ip, wb, ab, bb, gb_, gwn, goyn, goxn, g,
+                                                            rowy[j], tx0 + b, sc, HEAD);
+                        if (HEAD && x == tx0 + b) gocc[j] += c;
+                    }
+                } else if (flag) {
+                    const float c = bwd_outside_lane<R>(ip, wb, ab, bb, d[j][0], d[j][1], d[j][2], gwn,
+                                                        goyn, goxn, g, rowy[j],
+                                                        HEAD ? in_branch(x) : x,
+                                                        HEAD ? occv[j] : 1.f);
+                    if (HEAD) gocc[j] += c;
+                }
+            }
+            if constexpr (HEAD) {
+                if (ha.gocc)
+                    st_stream(ha.gocc + ((size_t)n * T + f) * pl + rf[j] + (unsigned)x, gocc[j]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// gradInput for k = 5, d = 1, C = 3, LDS-privatised.  (No reference counterpart: upstream returns
+// unfilled zeros, cupy_module/synth.py:333,391.)  The adjoint of the forward scatters, per tap,
+// gradOut_c * w * coef_q to the four clamped corners: 300 adds per pixel.  Straight to memory
+// that is 2.5 GB of float atomics per 1080p frame (>2 ms at the chip's ~1.3 TB/s atomic rate).
+// Here a workgroup accumulates its 64 x TH pixels into an LDS copy of the frame tile with
+// ds_add_u64 on fixed-point integers (planar [c][ly][lx]: a wave's lanes hit consecutive banks),
+// then flushes the tile with one global atomic per touched texel (~5 per pixel).  Taps displaced
+// beyond the tile radius are left out of the LDS pass and sent to memory individually afterwards
+// (same |offset| < R + 1 test in both passes, so every contribution lands exactly once).
+// FIXED (deterministic mode): the flush adds the integers into the int64 image of the workspace,
+// so the result does not depend on any order; otherwise each tile sum is converted to fp32 and
+// added to gradInput with float atomics.  Same tap-major streaming order as the other kernels.
+// ------------------------------------------------------------------------------------------
+
+// LDS accumulation is always 64-bit fixed point: ds_add_f32 turned out to execute lane-serially
+// on gfx950 (~170 cycles per wave instruction, measured: 3.1 ms per 1080p frame against 0.4 ms for
+// ds_add_u64), so even the non-deterministic mode sums integers on chip and only converts to
+// fp32 for the cross-workgroup adds.
+template <int R, int WAVES, int ROWS, bool FIXED>
+__global__ __launch_bounds__(64 * WAVES) void synth_gin_tiled(const float *__restrict__ w,
+                                                              const float *__restrict__ oy,
+                                                              const float *__restrict__ ox,
+                                                              const float *__restrict__ gout,
+                                                              float *__restrict__ gin,
+                                                              unsigned char *__restrict__ ws,
+                                                              Geom g, int count_bits)
+{
+    typedef unsigned long long acc_t;
+    constexpr int TH = WAVES * ROWS;
+    constexpr int LW = TileShape<R, TH>::LW, LH = TileShape<R, TH>::LH;
+    constexpr int CS = LH * LW;  // channel stride in the LDS tile
+    __shared__ acc_t acc[3 * CS];
+    const int tx0 = blockIdx.x * kTW, ty0 = blockIdx.y * TH, n = blockIdx.z;
+    const int wy = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int tid = wy * 64 + threadIdx.x;
+    const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
+    const int xr = tx0 + (int)threadIdx.x;          // this lane's own column
+    const bool lane_on = xr < g.W;                   // lanes past the right edge add nothing
+    const int x = min(xr, g.W - 1), px = x - tx0;
+    const size_t nb = (size_t)n * 25 * plane;
+    const float *wb = w + nb, *ab = oy + nb, *bb = ox + nb;
+    const float *gb_ = gout + (size_t)n * 3 * plane;
+
+    // ws: header with the two maxima (both modes) followed, in FIXED mode, by the int64 image
+    const int slog2 = det_scale_log2((const unsigned *)ws, count_bits);
+    const float scale = ldexpf(1.f, slog2);
+    acc_t *gfix = (acc_t *)((unsigned char *)ws + kDetHeaderBytes) + (size_t)n * 3 * iplane;
+    float *gflt = gin + (size_t)n * 3 * iplane;
+
+    int rowy[ROWS];
+    bool rowon[ROWS];  // wave-uniform: rows past the bottom edge add nothing
+    size_t roff[ROWS];
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+        const int yr = ty0 + wy + WAVES * j;
+        rowon[j] = yr < g.H;
+        rowy[j] = min(yr, g.H - 1);
+        roff[j] = (size_t)rowy[j] * g.W;
+    }
+
+    TapCol<ROWS> cur;
+    load_tap_col<ROWS>(cur, wb, ab, bb, plane, 0, roff, (unsigned)x);
+    for (int i = tid; i < 3 * CS; i += 64 * WAVES) acc[i] = 0;
+    __syncthreads();
+
+    float d[ROWS][3];
+    float mabs[ROWS];
+    int rowbase[ROWS];
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+        const float on = (lane_on && rowon[j]) ? scale : 0.f;  // masks edge duplicates
+        d[j][0] = ld_stream(gb_ + roff[j] + (unsigned)x) * on;
+        d[j][1] = ld_stream(gb_ + plane + roff[j] + (unsigned)x) * on;
+        d[j][2] = ld_stream(gb_ + 2 * plane + roff[j] + (unsigned)x) * on;
+        mabs[j] = 0.f;
+        rowbase[j] = (rowy[j] - ty0 + R) * LW + px + R;
+    }
+    static_for<0, 25>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        constexpr int r = t / 5, s = t % 5;
+        TapCol<ROWS> nxt;
+        if (t < 24) load_tap_col<ROWS>(nxt, wb, ab, bb, plane, t + 1, roff, (unsigned)x);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {
+            const float wv = cur.w[j], a = cur.a[j], b = cur.b[j];
+            const int ia = (int)a, ib = (int)b;
+            const float fa = a - (float)ia, fb = b - (float)ib;
+            mabs[j] = track_abs(mabs[j], a, b);
+            if (fmaxf(fabsf(a), fabsf(b)) < (float)(R + 1)) {  // footprint inside the tile
+                acc_t *p = acc + (__mul24(ia, LW) + ib + rowbase[j] + (r * LW + s));
+                const float ga = 1.f - fa, gb = 1.f - fb;
+                const float c00 = ga * gb, c10 = fa * gb, c01 = ga * fb, c11 = fa * fb;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float dw = d[j][c] * wv;
+                    atomicAdd(p + c * CS, to_fixed(dw * c00));  // ds_add_u64
+                    atomicAdd(p + c * CS + LW, to_fixed(dw * c10));
+                    atomicAdd(p + c * CS + 1, to_fixed(dw * c01));
+                    atomicAdd(p + c * CS + LW + 1, to_fixed(dw * c11));
+                }
+            }
+            asm volatile("" : "+v"(mabs[j]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+    });
+    __syncthreads();
+
+    // flush the tile: texel (ly, lx) is frame pixel (clamp(gy0 + ly), clamp(gx0 + lx))
+    const int gy0 = ty0 + g.oy0 - R, gx0 = tx0 + g.ox0 - R;
+    for (int i = tid; i < CS; i += 64 * WAVES) {
+        const int ly = i / LW, lx = i - ly * LW;
+        const int gy = clampi(gy0 + ly, 0, g.Hin - 1), gx = clampi(gx0 + lx, 0, g.Win - 1);
+        const size_t o = (size_t)gy * g.Win + gx;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const acc_t v = acc[c * CS + i];
+            if (v != 0) {
+                if constexpr (FIXED)
+                    atomicAdd(gfix + c * iplane + o, v);
+                else
+                    atomicAdd(gflt + c * iplane + o, (float)ldexp((double)(long long)v, -slog2));
+            }
+        }
+    }
+
+    // taps that left the tile: straight to memory, lane by lane (rare)
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+        if (!(mabs[j] < (float)(R + 1)) && lane_on && rowon[j]) {
+            const int y = rowy[j];
+            const size_t pix = roff[j] + x;
+#pragma unroll 1
+            for (int t = 0; t < 25; ++t) {
+                const size_t o = (size_t)t * plane + pix;
+                const float a = ab[o], b = bb[o];
+                if (fmaxf(fabsf(a), fabsf(b)) < (float)(R + 1)) continue;
+                const float wv = wb[o];
+                const int r = t / 5, s2 = t - 5 * r;
+                const TapIdx ti = tap_index(g, a, b, y + g.oy0 + r, x + g.ox0 + s2);
+                const float ga = 1.f - ti.fa, gb = 1.f - ti.fb;
+                const float c00 = ga * gb, c10 = ti.fa * gb, c01 = ga * ti.fb, c11 = ti.fa * ti.fb;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float dw = d[j][c] * wv;  // d carries the fixed-point scale
+                    if constexpr (FIXED) {
+                        acc_t *p = gfix + c * iplane;
+                        atomicAdd(p + ti.bl, to_fixed(dw * c00));
+                        atomicAdd(p + ti.tl, to_fixed(dw * c10));
+                        atomicAdd(p + ti.br, to_fixed(dw * c01));
+                        atomicAdd(p + ti.tr, to_fixed(dw * c11));
+                    } else {
+                        float *p = gflt + c * iplane;
+                        const float un = dw * ldexpf(1.f, -slog2);
+                        atomicAdd(p + ti.bl, un * c00);
+                        atomicAdd(p + ti.tl, un * c10);
+                        atomicAdd(p + ti.br, un * c01);
+                        atomicAdd(p + ti.tr, un * c11);
+                    }
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void offset_radius_kernel(const float *__restrict__ oy,
+                                                             const float *__restrict__ ox,
+                                                             size_t count, int *__restrict__ out)
+{
+    int m = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int ia = (int)oy[i], ib = (int)ox[i];
+        // |INT_MIN| does not fit: saturate
+        const int aa = ia == INT32_MIN ? INT32_MAX : abs(ia);
+        const int ab = ib == INT32_MIN ? INT32_MAX : abs(ib);
+        m = max(m, max(aa, ab));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
+}  // namespace
+#endif  // ARTEMIS_SYNTH_DEVICE_HPP

@@ -1,0 +1,119 @@
+// synth_tiles.hip -- the LDS-staged kernels for ONE tile radius (-DSYNTH_TILE_R=2|4|8|16):
+// explicit instantiations of the launchers declared in synth_device.hpp.  One object per radius
+// lets the heavily unrolled tap-major kernels compile in parallel.
+#include "synth_device.hpp"
+
+#ifndef SYNTH_TILE_R
+#error "compile with -DSYNTH_TILE_R=<radius>"
+#endif
+
+namespace {
+
+// Tile configuration per built radius (tools/ab.py compares builds in one process; the
+// SYNTH_* macros override the R <= 8 shape for such experiments).
+//   R <= 8 : 4 waves x 8 rows  = 64 x 32 pixels, LDS 47.9 / 55.4 / 72.1 KB, 2 workgroups per CU
+//   R = 16 : 8 waves x 4 rows  = 64 x 32 pixels, LDS 111.5 KB, 1 workgroup (8 waves) per CU
+#ifndef SYNTH_WAVES
+#define SYNTH_WAVES 4
+#endif
+#ifndef SYNTH_ROWS
+#define SYNTH_ROWS 8
+#endif
+#ifndef SYNTH_OCC
+#define SYNTH_OCC 2
+#endif
+
+template <int R>
+struct TileCfg {
+    static constexpr int WAVES = SYNTH_WAVES, ROWS = SYNTH_ROWS, OCC = SYNTH_OCC;
+};
+template <>
+struct TileCfg<16> {
+    static constexpr int WAVES = 8, ROWS = 4, OCC = 2;
+};
+
+}  // namespace
+
+namespace asynth {
+
+template <int R>
+void launch_fwd_tiled(const float *in, const float *w, const float *oy, const float *ox, float *out,
+                      const Geom &g, hipStream_t st)
+{
+    typedef TileCfg<R> T;
+    hipLaunchKernelGGL((synth_fwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false>),
+                       pixel_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, in, w, oy, ox, out,
+                       g, HeadArgs{});
+}
+
+template <int R>
+void launch_bwd_tiled(const float *in, const float *w, const float *oy, const float *ox,
+                      const float *gout, float *gw, float *goy, float *gox, const Geom &g,
+                      hipStream_t st)
+{
+    typedef TileCfg<R> T;
+    if (gw && goy && gox)
+        hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true, false>),
+                           pixel_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, in, w, oy, ox,
+                           gout, gw, goy, gox, g, HeadArgs{});
+    else
+        hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false, false>),
+                           pixel_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, in, w, oy, ox,
+                           gout, gw, goy, gox, g, HeadArgs{});
+}
+
+template <int R>
+void launch_head_fwd(const float *w, const float *oy, const float *ox, float *out, const Geom &g,
+                     const HeadArgs &ha, hipStream_t st)
+{
+    typedef TileCfg<R> T;
+    hipLaunchKernelGGL((synth_fwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true>),
+                       pixel_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, nullptr, w, oy, ox,
+                       out, g, ha);
+}
+
+template <int R>
+void launch_head_bwd(const float *w, const float *oy, const float *ox, const float *gout, float *gw,
+                     float *goy, float *gox, const Geom &g, const HeadArgs &ha, hipStream_t st)
+{
+    typedef TileCfg<R> T;
+    if (gw && goy && gox)
+        hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true, true>),
+                           pixel_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, nullptr, w, oy,
+                           ox, gout, gw, goy, gox, g, ha);
+    else
+        hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false, true>),
+                           pixel_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, nullptr, w, oy,
+                           ox, gout, gw, goy, gox, g, ha);
+}
+
+// gradInput tiles: 64 x 16 pixels, 64-bit accumulators (3 x 29 x 77 x 8 B = 53.6 KB at R = 4,
+// 128.5 KB at R = 16: one workgroup per CU)
+template <int R, bool FIXED>
+void launch_gin_tiled(const float *w, const float *oy, const float *ox, const float *gout, float *gin,
+                      unsigned char *ws, const Geom &g, int bits, hipStream_t st)
+{
+    constexpr int ROWS = 4;
+    hipLaunchKernelGGL((synth_gin_tiled<R, 4, ROWS, FIXED>), pixel_grid(g, 4 * ROWS), dim3(64, 4), 0, st,
+                       w, oy, ox, gout, gin, ws, g, bits);
+}
+
+
+template void launch_fwd_tiled<SYNTH_TILE_R>(const float *, const float *, const float *, const float *,
+                                             float *, const Geom &, hipStream_t);
+template void launch_bwd_tiled<SYNTH_TILE_R>(const float *, const float *, const float *, const float *,
+                                             const float *, float *, float *, float *, const Geom &,
+                                             hipStream_t);
+template void launch_head_fwd<SYNTH_TILE_R>(const float *, const float *, const float *, float *,
+                                            const Geom &, const HeadArgs &, hipStream_t);
+template void launch_head_bwd<SYNTH_TILE_R>(const float *, const float *, const float *, const float *,
+                                            float *, float *, float *, const Geom &, const HeadArgs &,
+                                            hipStream_t);
+template void launch_gin_tiled<SYNTH_TILE_R, false>(const float *, const float *, const float *,
+                                                    const float *, float *, unsigned char *,
+                                                    const Geom &, int, hipStream_t);
+template void launch_gin_tiled<SYNTH_TILE_R, true>(const float *, const float *, const float *,
+                                                   const float *, float *, unsigned char *,
+                                                   const Geom &, int, hipStream_t);
+
+}  // namespace asynth

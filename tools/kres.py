@@ -2,7 +2,8 @@
 """Compile the HIP source for gfx950 with -save-temps and print, per kernel, the register /
 LDS / scratch budget and an instruction-class census of its ISA (developer tool; CPU only).
 
-usage: python tools/kres.py [filter-substring] [--flags "..."]
+usage: python tools/kres.py [filter-substring] [--radius R | --host] [--flags "..."]
+(default: the tile translation unit for radius 8; --host: synth_kernels.hip with the direct kernels)
 """
 import collections
 import os
@@ -12,12 +13,13 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "artemis_amd", "csrc", "synth_kernels.hip")
+CSRC = os.path.join(ROOT, "artemis_amd", "csrc")
 
 
 def main():
     filt = ""
     extra = []
+    radius = 8
     args = sys.argv[1:]
     while args:
         a = args.pop(0)
@@ -25,11 +27,17 @@ def main():
             extra = args.pop(0).split()
         elif a == "--keep":
             pass
+        elif a == "--radius":
+            radius = int(args.pop(0))
+        elif a == "--host":
+            radius = None
         else:
             filt = a
     tmp = tempfile.mkdtemp(prefix="kres_")
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-c", "-munsafe-fp-atomics", "-ffp-contract=on",
-           "-I" + os.path.join(ROOT, "include"), "-save-temps", "-o", "k.o", SRC] + extra
+           "-I" + os.path.join(ROOT, "include"), "-save-temps", "-o", "k.o"] + \
+        ([os.path.join(CSRC, "synth_kernels.hip")] if radius is None else
+         [os.path.join(CSRC, "synth_tiles.hip"), f"-DSYNTH_TILE_R={radius}"]) + extra
     r = subprocess.run(cmd, cwd=tmp, capture_output=True, text=True)
     if r.returncode:
         print(r.stderr)
