@@ -75,6 +75,26 @@ inline dim3 pixel_grid(const Geom &g, int rows_per_block)
                 (unsigned)g.N);
 }
 
+// XCD-aware tile order (SYNTH_XCD_REMAP, default on): workgroups are dispatched round-robin over
+// the 8 XCDs (workgroup id % 8), each with its own L2.  XCD i gets the i-th contiguous band of
+// tiles, so neighbouring tiles -- which share their frame halo and the DRAM pages of the plane
+// rows they split -- run on the same XCD at about the same time.  The grid is 1-D in x, padded to
+// a multiple of 8; a workgroup whose tile index falls past the end exits at once.  Measured at
+// 1080p: forward 114.4 -> 111.6 us, backward 251.7 -> 249.0 us at R = 8; 116.2 -> 112.0 and
+// 257.8 -> 251.2 us at R = 16.  Correct under any dispatch order.
+#ifndef SYNTH_XCD_REMAP
+#define SYNTH_XCD_REMAP 1
+#endif
+inline dim3 tile_grid(const Geom &g, int rows_per_block)
+{
+#if SYNTH_XCD_REMAP
+    const unsigned nb = (unsigned)((g.W + 63) / 64) * (unsigned)((g.H + rows_per_block - 1) / rows_per_block);
+    return dim3(((nb + 7) / 8) * 8, 1, (unsigned)g.N);
+#else
+    return pixel_grid(g, rows_per_block);
+#endif
+}
+
 }  // namespace asynth
 
 namespace {
@@ -83,6 +103,26 @@ using asynth::Geom;
 using asynth::HeadArgs;
 using asynth::kMaxFrames;
 using asynth::pixel_grid;
+
+// tile origin of this workgroup; false: no tile (only with SYNTH_XCD_REMAP)
+template <int TH>
+__device__ __forceinline__ bool tile_origin(const Geom &g, int &tx0, int &ty0)
+{
+#if SYNTH_XCD_REMAP
+    const unsigned tiles_x = (unsigned)(g.W + 63) / 64, tiles_y = (unsigned)(g.H + TH - 1) / TH;
+    const unsigned nb = tiles_x * tiles_y, per = (nb + 7) / 8;
+    const unsigned t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (t >= nb) return false;
+    const unsigned ty = t / tiles_x;
+    tx0 = (int)(t - ty * tiles_x) * 64;
+    ty0 = (int)ty * TH;
+    return true;
+#else
+    tx0 = blockIdx.x * 64;
+    ty0 = blockIdx.y * TH;
+    return true;
+#endif
+}
 
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
@@ -774,7 +814,9 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
     constexpr int LW = TileShape<R, TH>::LW, LH = TileShape<R, TH>::LH;
     __shared__ f32x4 tile[LH * LW];
     const lds_f32x4 *ltile = (const lds_f32x4 *)tile;
-    const int tx0 = blockIdx.x * kTW, ty0 = blockIdx.y * TH, n = blockIdx.z;
+    int tx0, ty0;
+    if (!tile_origin<TH>(g, tx0, ty0)) return;
+    const int n = blockIdx.z;
     const int wy = __builtin_amdgcn_readfirstlane(threadIdx.y);
     const int tid = wy * 64 + threadIdx.x;
     const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
@@ -934,7 +976,9 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
     constexpr int LW = TileShape<R, TH>::LW, LH = TileShape<R, TH>::LH;
     __shared__ f32x4 tile[LH * LW];
     const lds_f32x4 *ltile = (const lds_f32x4 *)tile;
-    const int tx0 = blockIdx.x * kTW, ty0 = blockIdx.y * TH, n = blockIdx.z;
+    int tx0, ty0;
+    if (!tile_origin<TH>(g, tx0, ty0)) return;
+    const int n = blockIdx.z;
     const int wy = __builtin_amdgcn_readfirstlane(threadIdx.y);
     const int tid = wy * 64 + threadIdx.x;
     const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;

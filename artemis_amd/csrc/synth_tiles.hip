@@ -42,7 +42,7 @@ void launch_fwd_tiled(const float *in, const float *w, const float *oy, const fl
 {
     typedef TileCfg<R> T;
     hipLaunchKernelGGL((synth_fwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false>),
-                       pixel_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, in, w, oy, ox, out,
+                       tile_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, in, w, oy, ox, out,
                        g, HeadArgs{});
 }
 
@@ -54,11 +54,11 @@ void launch_bwd_tiled(const float *in, const float *w, const float *oy, const fl
     typedef TileCfg<R> T;
     if (gw && goy && gox)
         hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true, false>),
-                           pixel_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, in, w, oy, ox,
+                           tile_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, in, w, oy, ox,
                            gout, gw, goy, gox, g, HeadArgs{});
     else
         hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false, false>),
-                           pixel_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, in, w, oy, ox,
+                           tile_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, in, w, oy, ox,
                            gout, gw, goy, gox, g, HeadArgs{});
 }
 
@@ -68,7 +68,7 @@ void launch_head_fwd(const float *w, const float *oy, const float *ox, float *ou
 {
     typedef TileCfg<R> T;
     hipLaunchKernelGGL((synth_fwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true>),
-                       pixel_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, nullptr, w, oy, ox,
+                       tile_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, nullptr, w, oy, ox,
                        out, g, ha);
 }
 
@@ -79,11 +79,11 @@ void launch_head_bwd(const float *w, const float *oy, const float *ox, const flo
     typedef TileCfg<R> T;
     if (gw && goy && gox)
         hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true, true>),
-                           pixel_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, nullptr, w, oy,
+                           tile_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, nullptr, w, oy,
                            ox, gout, gw, goy, gox, g, ha);
     else
         hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false, true>),
-                           pixel_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, nullptr, w, oy,
+                           tile_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, nullptr, w, oy,
                            ox, gout, gw, goy, gox, g, ha);
 }
 
