@@ -17,6 +17,8 @@ RADIUS_DEFAULT = -1
 RADIUS_NONE = 0
 GIN_ATOMIC = 0
 GIN_DETERMINISTIC = 1
+FRAME_F32 = 0
+FRAME_BF16 = 1
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -26,11 +28,11 @@ SIGNATURES = {
     "artemis_synth_forward": (_i, [_vp] * 5 + [_i] * 7 + [_vp]),
     "artemis_synth_backward": (_i, [_vp] * 9 + [_i] * 8 + [_vp, ctypes.c_size_t, _vp]),
     "artemis_synth_backward_workspace_bytes": (ctypes.c_size_t, [_i] * 7),
-    "artemis_synth_forward_ex": (_i, [_vp] * 5 + [_i] * 11 + [_vp]),
-    "artemis_synth_backward_ex": (_i, [_vp] * 9 + [_i] * 12 + [_vp, ctypes.c_size_t, _vp]),
+    "artemis_synth_forward_ex": (_i, [_vp] * 5 + [_i] * 12 + [_vp]),
+    "artemis_synth_backward_ex": (_i, [_vp] * 9 + [_i] * 13 + [_vp, ctypes.c_size_t, _vp]),
     "artemis_synth_backward_workspace_bytes_ex": (ctypes.c_size_t, [_i] * 9),
-    "artemis_synth_head_forward": (_i, [_vp, _i] + [_vp] * 5 + [_i] * 8 + [_vp]),
-    "artemis_synth_head_backward": (_i, [_vp, _i] + [_vp] * 9 + [_i] * 8 + [_vp]),
+    "artemis_synth_head_forward": (_i, [_vp, _i] + [_vp] * 5 + [_i] * 9 + [_vp]),
+    "artemis_synth_head_backward": (_i, [_vp, _i] + [_vp] * 9 + [_i] * 9 + [_vp]),
     "artemis_synth_offset_radius": (_i, [_vp, _vp, ctypes.c_size_t, _vp, _vp]),
     "artemis_synth_version": (ctypes.c_char_p, []),
     "artemis_synth_last_error": (ctypes.c_char_p, []),

@@ -47,17 +47,22 @@ def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
     jobs = [(SRC, os.path.join(OBJ_DIR, "synth_kernels.o"), [])]
     jobs += [(TILES_SRC, os.path.join(OBJ_DIR, f"synth_tiles_r{r}.o"), [f"-DSYNTH_TILE_R={r}"])
              for r in TILE_RADII]
-    procs = []
-    for src, obj, defs in jobs:
+    jobs += [(TILES_SRC, os.path.join(OBJ_DIR, f"synth_tiles_r{r}_bf16.o"),
+              [f"-DSYNTH_TILE_R={r}", "-DSYNTH_TILE_BF16=1"]) for r in TILE_RADII]
+    workers = max(1, min(len(jobs), int(os.environ.get("MAX_JOBS", os.cpu_count() or 1))))
+
+    def compile_one(job):
+        src, obj, defs = job
         cmd = [hipcc, *HIPCC_FLAGS, *extra_flags, *defs, "-I" + INCLUDE, "-c", "-o", obj, src]
         if verbose:
-            print(" ".join(cmd))
-        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                                            text=True)))
-    for cmd, pr in procs:
-        _, err = pr.communicate()
-        if pr.returncode != 0:
-            raise RuntimeError("hipcc failed: " + " ".join(cmd) + "\n" + err)
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed: " + " ".join(cmd) + "\n" + r.stderr)
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(workers) as pool:
+        list(pool.map(compile_one, jobs))
     link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + [j[1] for j in jobs]
     if verbose:
         print(" ".join(link))

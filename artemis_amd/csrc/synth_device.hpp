@@ -43,26 +43,31 @@ struct Geom {
 
 constexpr int kMaxFrames = 8;
 
+// Frame element types: fp32 (the reference's) or bf16 bit patterns (BASELINE configs[4]: "bf16
+// frames / fp32 accumulate").  A bf16 texel is widened exactly when it is staged or gathered; all
+// arithmetic stays fp32.
+typedef unsigned short bf16_t;
+
 // arguments of the fused ChronoSynth head kernels (ignored by the single-frame instantiations)
 struct HeadArgs {
-    const float *frame[kMaxFrames];  // T frames, each (N, 3, Hin, Win)
+    const void *frame[kMaxFrames];   // T frames, each (N, 3, Hin, Win), fp32 or bf16
     const float *occ;                // (N, T, H, W)
     float *gocc;                     // backward only: (N, T, H, W) or null
     int T;
 };
 
 // Launchers of the LDS-staged kernels, one explicit instantiation per radius in synth_tiles.hip.
-template <int R>
-void launch_fwd_tiled(const float *in, const float *w, const float *oy, const float *ox, float *out,
+template <int R, class FT>
+void launch_fwd_tiled(const FT *in, const float *w, const float *oy, const float *ox, float *out,
                       const Geom &g, hipStream_t st);
-template <int R>
-void launch_bwd_tiled(const float *in, const float *w, const float *oy, const float *ox,
+template <int R, class FT>
+void launch_bwd_tiled(const FT *in, const float *w, const float *oy, const float *ox,
                       const float *gout, float *gw, float *goy, float *gox, const Geom &g,
                       hipStream_t st);
-template <int R>
+template <int R, class FT>
 void launch_head_fwd(const float *w, const float *oy, const float *ox, float *out, const Geom &g,
                      const HeadArgs &ha, hipStream_t st);
-template <int R>
+template <int R, class FT>
 void launch_head_bwd(const float *w, const float *oy, const float *ox, const float *gout, float *gw,
                      float *goy, float *gox, const Geom &g, const HeadArgs &ha, hipStream_t st);
 template <int R, bool FIXED>
@@ -103,6 +108,20 @@ using asynth::Geom;
 using asynth::HeadArgs;
 using asynth::kMaxFrames;
 using asynth::pixel_grid;
+using asynth::bf16_t;
+
+// A frame as the gather code sees it: indexable, offsettable, yields fp32.  fp32 frames are plain
+// pointers; bf16 frames widen on load (global_load_ushort + shift).
+struct Bf16View {
+    const bf16_t *p;
+    __device__ __forceinline__ float operator[](size_t i) const
+    {
+        return __uint_as_float((unsigned)p[i] << 16);
+    }
+    __device__ __forceinline__ Bf16View operator+(size_t o) const { return Bf16View{p + o}; }
+};
+__device__ __forceinline__ const float *frame_view(const float *p) { return p; }
+__device__ __forceinline__ Bf16View frame_view(const bf16_t *p) { return Bf16View{p}; }
 
 // tile origin of this workgroup; false: no tile (only with SYNTH_XCD_REMAP)
 template <int TH>
@@ -518,14 +537,15 @@ __device__ __forceinline__ bool tap_in_tile(float a, float b)
 }
 
 // Contribution of ONE tap (clamped global gathers), channels 0..2.
-__device__ __forceinline__ Float3 fwd_tap_global(const float *__restrict__ ip, const Geom &g, float wv,
+template <class FP>
+__device__ __forceinline__ Float3 fwd_tap_global(FP ip, const Geom &g, float wv,
                                                  float a, float b, int yb, int xb)
 {
     const size_t iplane = (size_t)g.Hin * g.Win;
     const TapIdx ti = tap_index(g, a, b, yb, xb);
     const float ga = 1.f - ti.fa, gb = 1.f - ti.fb;
     const float c00 = ga * gb, c10 = ti.fa * gb, c01 = ga * ti.fb, c11 = ti.fa * ti.fb;
-    const float *p0 = ip, *p1 = ip + iplane, *p2 = ip + 2 * iplane;
+    const FP p0 = ip, p1 = ip + iplane, p2 = ip + 2 * iplane;
     Float3 o;
     o.x = wv * (p0[ti.bl] * c00 + p0[ti.tl] * c10 + p0[ti.br] * c01 + p0[ti.tr] * c11);
     o.y = wv * (p1[ti.bl] * c00 + p1[ti.tl] * c10 + p1[ti.br] * c01 + p1[ti.tr] * c11);
@@ -535,8 +555,8 @@ __device__ __forceinline__ Float3 fwd_tap_global(const float *__restrict__ ip, c
 
 // Sum over the out-of-tile taps of pixel (y, xs), computed by the whole wave (lane l < 25 owns
 // tap l).  wb/ab/bb: tap 0 of the sample's planes; ip: the sample's frame.  Result in every lane.
-template <int R>
-__device__ __forceinline__ Float3 fwd_outside_coop(const float *__restrict__ ip,
+template <int R, class FP>
+__device__ __forceinline__ Float3 fwd_outside_coop(FP ip,
                                                    const float *__restrict__ wb,
                                                    const float *__restrict__ ab,
                                                    const float *__restrict__ bb, const Geom &g, int y,
@@ -560,8 +580,8 @@ __device__ __forceinline__ Float3 fwd_outside_coop(const float *__restrict__ ip,
 }
 
 // The same sum by one lane for its own pixel (used when many lanes of the wave are flagged).
-template <int R>
-__device__ __forceinline__ Float3 fwd_outside_lane(const float *__restrict__ ip,
+template <int R, class FP>
+__device__ __forceinline__ Float3 fwd_outside_lane(FP ip,
                                                    const float *__restrict__ wp,
                                                    const float *__restrict__ ap,
                                                    const float *__restrict__ bp, const Geom &g, int y,
@@ -590,7 +610,8 @@ __device__ __forceinline__ Float3 fwd_outside_lane(const float *__restrict__ ip,
 // (tap, y, x) in the sample's 25-plane tensors.  The three gradients are stored times `scale`
 // (the occlusion weight in the fused head, 1 otherwise); returns w * (unscaled gradWeight), the
 // tap's share of the occlusion gradient.
-__device__ __forceinline__ float bwd_tap_global(const float *__restrict__ ip, const Geom &g, float wv,
+template <class FP>
+__device__ __forceinline__ float bwd_tap_global(FP ip, const Geom &g, float wv,
                                                 float a, float b, float d0, float d1, float d2, int yb,
                                                 int xb, float *__restrict__ gwn,
                                                 float *__restrict__ goyn, float *__restrict__ goxn,
@@ -598,7 +619,7 @@ __device__ __forceinline__ float bwd_tap_global(const float *__restrict__ ip, co
 {
     const size_t iplane = (size_t)g.Hin * g.Win;
     const TapIdx ti = tap_index(g, a, b, yb, xb);
-    const float *p0 = ip, *p1 = ip + iplane, *p2 = ip + 2 * iplane;
+    const FP p0 = ip, p1 = ip + iplane, p2 = ip + 2 * iplane;
     const float pbl = d0 * p0[ti.bl] + d1 * p1[ti.bl] + d2 * p2[ti.bl];
     const float ptl = d0 * p0[ti.tl] + d1 * p1[ti.tl] + d2 * p2[ti.tl];
     const float pbr = d0 * p0[ti.br] + d1 * p1[ti.br] + d2 * p2[ti.br];
@@ -617,8 +638,8 @@ __device__ __forceinline__ float bwd_tap_global(const float *__restrict__ ip, co
 // Out-of-tile taps of pixel (y, xs) recomputed and stored by the whole wave.
 // gn: the sample's gradOutput planes; gwn/goyn/goxn: tap 0 of the sample's gradient planes.
 // Returns (in every lane) the sum over those taps of w * unscaled gradWeight.
-template <int R>
-__device__ __forceinline__ float bwd_outside_coop(const float *__restrict__ ip,
+template <int R, class FP>
+__device__ __forceinline__ float bwd_outside_coop(FP ip,
                                                   const float *__restrict__ wb,
                                                   const float *__restrict__ ab,
                                                   const float *__restrict__ bb,
@@ -643,8 +664,8 @@ __device__ __forceinline__ float bwd_outside_coop(const float *__restrict__ ip,
     return want_sum ? wave_sum(c) : 0.f;
 }
 
-template <int R>
-__device__ __forceinline__ float bwd_outside_lane(const float *__restrict__ ip,
+template <int R, class FP>
+__device__ __forceinline__ float bwd_outside_lane(FP ip,
                                                   const float *__restrict__ wb,
                                                   const float *__restrict__ ab,
                                                   const float *__restrict__ bb, float d0, float d1,
@@ -712,8 +733,8 @@ __device__ __forceinline__ void load_tap_col(TapCol<ROWS> &t, const float *__res
 // every texel, which serialises ~14 L2 round trips (~10 us) at the head of every workgroup.
 constexpr int kFillBatch = 7;
 
-template <int R, int TH, int THREADS>
-__device__ __forceinline__ void fill_tile_n(f32x4 *tile, const float *__restrict__ ip, const Geom &g,
+template <int R, int TH, int THREADS, class FP>
+__device__ __forceinline__ void fill_tile_n(f32x4 *tile, FP ip, const Geom &g,
                                             int gy0, int gx0, int tid)
 {
     constexpr int LW = TileShape<R, TH>::LW, LH = TileShape<R, TH>::LH;
@@ -805,9 +826,9 @@ __device__ __forceinline__ int in_branch(int v)
 }
 
 
-template <int R, int WAVES, int ROWS, int OCC, bool HEAD>
+template <int R, int WAVES, int ROWS, int OCC, bool HEAD, class FT>
 __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
-    const float *__restrict__ in, const float *__restrict__ w, const float *__restrict__ oy,
+    const FT *__restrict__ in, const float *__restrict__ w, const float *__restrict__ oy,
     const float *__restrict__ ox, float *__restrict__ out, Geom g, HeadArgs ha)
 {
     constexpr int TH = WAVES * ROWS;
@@ -852,7 +873,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
 #pragma unroll
             for (int j = 0; j < ROWS; ++j) rf[j] = per_frame(rf[j]);
         }
-        const float *ip = (HEAD ? ha.frame[f] : in) + (size_t)n * 3 * iplane;
+        const auto ip = frame_view((HEAD ? (const FT *)ha.frame[f] : in) + (size_t)n * 3 * iplane);
         const size_t nb = ((size_t)n * T + f) * 25 * pl;
         const float *wb = w + nb, *ab = oy + nb, *bb = ox + nb;
 
@@ -966,9 +987,9 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
 // out = sum_f occ_f * S_f; per frame the kernel forms the unscaled tap gradients from it, stores
 // them times occ_f into slice [n, f] of the 5-D gradient tensors in place, and accumulates
 // gocc[n, f] = sum_c gradOutput_c * S_f,c = sum_t w_t * (unscaled gradWeight_t) in registers.
-template <int R, int WAVES, int ROWS, int OCC, bool ALL, bool HEAD>
+template <int R, int WAVES, int ROWS, int OCC, bool ALL, bool HEAD, class FT>
 __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
-    const float *__restrict__ in, const float *__restrict__ w, const float *__restrict__ oy,
+    const FT *__restrict__ in, const float *__restrict__ w, const float *__restrict__ oy,
     const float *__restrict__ ox, const float *__restrict__ gout, float *__restrict__ gw,
     float *__restrict__ goy, float *__restrict__ gox, Geom g, HeadArgs ha)
 {
@@ -1008,7 +1029,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
 #pragma unroll
             for (int j = 0; j < ROWS; ++j) rf[j] = per_frame(rf[j]);
         }
-        const float *ip = (HEAD ? ha.frame[f] : in) + (size_t)n * 3 * iplane;
+        const auto ip = frame_view((HEAD ? (const FT *)ha.frame[f] : in) + (size_t)n * 3 * iplane);
         const size_t nb = ((size_t)n * T + f) * 25 * pl;
         const float *wb = w + nb, *ab = oy + nb, *bb = ox + nb;
 

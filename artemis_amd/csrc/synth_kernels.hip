@@ -125,6 +125,79 @@ int reduce_blocks(size_t count)
     return (int)(b < 2048 ? (b ? b : 1) : 2048);
 }
 
+// frame_dtype checks shared by the entry points that accept bf16 frames
+int check_frame_dtype(const Geom &g, int frame_dtype, const char *what)
+{
+    if (frame_dtype != ARTEMIS_SYNTH_FRAME_F32 && frame_dtype != ARTEMIS_SYNTH_FRAME_BF16)
+        return fail(hipErrorInvalidValue, "%s: unknown frame_dtype %d", what, frame_dtype);
+    if (frame_dtype == ARTEMIS_SYNTH_FRAME_BF16 && !tiled_ok(g))
+        return fail(hipErrorInvalidValue,
+                    "%s: bf16 frames are built for k = 5, d = 1, C = 3 only (got k=%d d=%d C=%d)", what,
+                    g.k, g.d, g.C);
+    return 0;
+}
+
+// radius of the LDS-staged kernel to run, 0 = direct kernels (fp32 frames only)
+int tiled_radius(const Geom &g, int tile_radius, int frame_dtype)
+{
+    if (!tiled_ok(g)) return 0;
+    int R = pick_radius(tile_radius);
+    if (R == 0 && frame_dtype == ARTEMIS_SYNTH_FRAME_BF16) R = pick_radius(ARTEMIS_SYNTH_RADIUS_DEFAULT);
+    return R;
+}
+
+template <class FT>
+void dispatch_fwd_tiled(int R, const void *input, const float *weight, const float *offset_y,
+                               const float *offset_x, float *output, const Geom &g, hipStream_t st)
+{
+    const FT *in = (const FT *)input;
+    switch (R) {
+    case 2: launch_fwd_tiled<2, FT>(in, weight, offset_y, offset_x, output, g, st); break;
+    case 4: launch_fwd_tiled<4, FT>(in, weight, offset_y, offset_x, output, g, st); break;
+    case 8: launch_fwd_tiled<8, FT>(in, weight, offset_y, offset_x, output, g, st); break;
+    default: launch_fwd_tiled<16, FT>(in, weight, offset_y, offset_x, output, g, st); break;
+    }
+}
+
+template <class FT>
+void dispatch_bwd_tiled(int R, const void *input, const float *weight, const float *offset_y,
+                               const float *offset_x, const float *grad_output, float *gw, float *goy,
+                               float *gox, const Geom &g, hipStream_t st)
+{
+    const FT *in = (const FT *)input;
+    switch (R) {
+    case 2: launch_bwd_tiled<2, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, st); break;
+    case 4: launch_bwd_tiled<4, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, st); break;
+    case 8: launch_bwd_tiled<8, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, st); break;
+    default: launch_bwd_tiled<16, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, st); break;
+    }
+}
+
+template <class FT>
+void dispatch_head_fwd(int R, const float *w, const float *oy, const float *ox, float *out,
+                              const Geom &g, const HeadArgs &ha, hipStream_t st)
+{
+    switch (R) {
+    case 2: launch_head_fwd<2, FT>(w, oy, ox, out, g, ha, st); break;
+    case 4: launch_head_fwd<4, FT>(w, oy, ox, out, g, ha, st); break;
+    case 8: launch_head_fwd<8, FT>(w, oy, ox, out, g, ha, st); break;
+    default: launch_head_fwd<16, FT>(w, oy, ox, out, g, ha, st); break;
+    }
+}
+
+template <class FT>
+void dispatch_head_bwd(int R, const float *w, const float *oy, const float *ox,
+                              const float *gout, float *gw, float *goy, float *gox, const Geom &g,
+                              const HeadArgs &ha, hipStream_t st)
+{
+    switch (R) {
+    case 2: launch_head_bwd<2, FT>(w, oy, ox, gout, gw, goy, gox, g, ha, st); break;
+    case 4: launch_head_bwd<4, FT>(w, oy, ox, gout, gw, goy, gox, g, ha, st); break;
+    case 8: launch_head_bwd<8, FT>(w, oy, ox, gout, gw, goy, gox, g, ha, st); break;
+    default: launch_head_bwd<16, FT>(w, oy, ox, gout, gw, goy, gox, g, ha, st); break;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -136,22 +209,24 @@ const char *artemis_synth_version(void)
 
 const char *artemis_synth_last_error(void) { return g_last_error; }
 
-static int run_forward(const Geom &g, int rc, const float *input, const float *weight,
+static int run_forward(const Geom &g, int rc, const void *input_any, const float *weight,
                        const float *offset_y, const float *offset_x, float *output, int tile_radius,
-                       void *stream)
+                       int frame_dtype, void *stream)
 {
     if (rc > 0) return rc;
+    if (const int e = check_frame_dtype(g, frame_dtype, "artemis_synth_forward")) return e;
     if (rc < 0) return 0;
-    if (!input || !weight || !offset_y || !offset_x || !output)
+    if (!input_any || !weight || !offset_y || !offset_x || !output)
         return fail(hipErrorInvalidValue, "artemis_synth_forward: NULL tensor pointer");
     hipStream_t st = (hipStream_t)stream;
-    const int R = tiled_ok(g) ? pick_radius(tile_radius) : 0;
-    switch (R) {
-    case 2: launch_fwd_tiled<2>(input, weight, offset_y, offset_x, output, g, st); break;
-    case 4: launch_fwd_tiled<4>(input, weight, offset_y, offset_x, output, g, st); break;
-    case 8: launch_fwd_tiled<8>(input, weight, offset_y, offset_x, output, g, st); break;
-    case 16: launch_fwd_tiled<16>(input, weight, offset_y, offset_x, output, g, st); break;
-    default:
+    const int R = tiled_radius(g, tile_radius, frame_dtype);
+    if (R > 0) {
+        if (frame_dtype == ARTEMIS_SYNTH_FRAME_BF16)
+            dispatch_fwd_tiled<asynth::bf16_t>(R, input_any, weight, offset_y, offset_x, output, g, st);
+        else
+            dispatch_fwd_tiled<float>(R, input_any, weight, offset_y, offset_x, output, g, st);
+    } else {
+        const float *input = (const float *)input_any;
         for (int c0 = 0; c0 < g.C; c0 += 4) {
             const int ch = g.C - c0 < 4 ? g.C - c0 : 4;
             const dim3 grid = pixel_grid(g, 4), block(64, 4);
@@ -168,17 +243,19 @@ int artemis_synth_forward(const float *input, const float *weight, const float *
 {
     Geom g;
     const int rc = make_geom(g, N, C, H, W, k, d);
-    return run_forward(g, rc, input, weight, offset_y, offset_x, output, tile_radius, stream);
+    return run_forward(g, rc, input, weight, offset_y, offset_x, output, tile_radius,
+                       ARTEMIS_SYNTH_FRAME_F32, stream);
 }
 
-int artemis_synth_forward_ex(const float *input, const float *weight, const float *offset_y,
+int artemis_synth_forward_ex(const void *input, const float *weight, const float *offset_y,
                              const float *offset_x, float *output, int N, int C, int H, int W, int k,
-                             int d, int in_H, int in_W, int org_y, int org_x, int tile_radius,
-                             void *stream)
+                             int d, int in_H, int in_W, int org_y, int org_x, int frame_dtype,
+                             int tile_radius, void *stream)
 {
     Geom g;
     const int rc = make_geom_ex(g, N, C, H, W, k, d, in_H, in_W, org_y, org_x);
-    return run_forward(g, rc, input, weight, offset_y, offset_x, output, tile_radius, stream);
+    return run_forward(g, rc, input, weight, offset_y, offset_x, output, tile_radius, frame_dtype,
+                       stream);
 }
 
 size_t artemis_synth_backward_workspace_bytes(int N, int C, int H, int W, int k, int d,
@@ -198,13 +275,15 @@ size_t artemis_synth_backward_workspace_bytes_ex(int N, int C, int H, int W, int
     return ws_bytes_needed(g, gin_mode, tiled_ok(g) ? 1 : 0);
 }
 
-static int run_backward(const Geom &g, int rc, const float *input, const float *weight,
+static int run_backward(const Geom &g, int rc, const void *input_any, const float *weight,
                         const float *offset_y, const float *offset_x, const float *grad_output,
                         float *grad_input, float *grad_weight, float *grad_offset_y,
-                        float *grad_offset_x, int gin_mode, int tile_radius, void *workspace,
-                        size_t workspace_bytes, void *stream)
+                        float *grad_offset_x, int gin_mode, int tile_radius, int frame_dtype,
+                        void *workspace, size_t workspace_bytes, void *stream)
 {
     if (rc > 0) return rc;
+    if (const int e = check_frame_dtype(g, frame_dtype, "artemis_synth_backward")) return e;
+    const float *input = (const float *)input_any;
     const int N = g.N, C = g.C, H = g.H, W = g.W, k = g.k;
     if (gin_mode != ARTEMIS_SYNTH_GIN_ATOMIC && gin_mode != ARTEMIS_SYNTH_GIN_DETERMINISTIC)
         return fail(hipErrorInvalidValue, "artemis_synth_backward: unknown gin_mode %d", gin_mode);
@@ -222,13 +301,15 @@ static int run_backward(const Geom &g, int rc, const float *input, const float *
         return fail(hipErrorInvalidValue, "artemis_synth_backward: NULL tensor pointer");
 
     if (grad_weight || grad_offset_y || grad_offset_x) {
-        const int R = tiled_ok(g) ? pick_radius(tile_radius) : 0;
-        switch (R) {
-        case 2: launch_bwd_tiled<2>(input, weight, offset_y, offset_x, grad_output, grad_weight, grad_offset_y, grad_offset_x, g, st); break;
-        case 4: launch_bwd_tiled<4>(input, weight, offset_y, offset_x, grad_output, grad_weight, grad_offset_y, grad_offset_x, g, st); break;
-        case 8: launch_bwd_tiled<8>(input, weight, offset_y, offset_x, grad_output, grad_weight, grad_offset_y, grad_offset_x, g, st); break;
-        case 16: launch_bwd_tiled<16>(input, weight, offset_y, offset_x, grad_output, grad_weight, grad_offset_y, grad_offset_x, g, st); break;
-        default:
+        const int R = tiled_radius(g, tile_radius, frame_dtype);
+        if (R > 0) {
+            if (frame_dtype == ARTEMIS_SYNTH_FRAME_BF16)
+                dispatch_bwd_tiled<asynth::bf16_t>(R, input_any, weight, offset_y, offset_x, grad_output,
+                                                   grad_weight, grad_offset_y, grad_offset_x, g, st);
+            else
+                dispatch_bwd_tiled<float>(R, input_any, weight, offset_y, offset_x, grad_output,
+                                          grad_weight, grad_offset_y, grad_offset_x, g, st);
+        } else {
             if (k == 5 && C == 3)
                 hipLaunchKernelGGL((synth_bwd_direct<3, 5>), pixel_grid(g, 4), dim3(64, 4), 0, st, input,
                                    weight, offset_y, offset_x, grad_output, grad_weight,
@@ -310,28 +391,28 @@ int artemis_synth_backward(const float *input, const float *weight, const float 
     Geom g;
     const int rc = make_geom(g, N, C, H, W, k, d);
     return run_backward(g, rc, input, weight, offset_y, offset_x, grad_output, grad_input,
-                        grad_weight, grad_offset_y, grad_offset_x, gin_mode, tile_radius, workspace,
-                        workspace_bytes, stream);
+                        grad_weight, grad_offset_y, grad_offset_x, gin_mode, tile_radius,
+                        ARTEMIS_SYNTH_FRAME_F32, workspace, workspace_bytes, stream);
 }
 
-int artemis_synth_backward_ex(const float *input, const float *weight, const float *offset_y,
+int artemis_synth_backward_ex(const void *input, const float *weight, const float *offset_y,
                               const float *offset_x, const float *grad_output, float *grad_input,
                               float *grad_weight, float *grad_offset_y, float *grad_offset_x, int N,
                               int C, int H, int W, int k, int d, int in_H, int in_W, int org_y,
-                              int org_x, int gin_mode, int tile_radius, void *workspace,
-                              size_t workspace_bytes, void *stream)
+                              int org_x, int frame_dtype, int gin_mode, int tile_radius,
+                              void *workspace, size_t workspace_bytes, void *stream)
 {
     Geom g;
     const int rc = make_geom_ex(g, N, C, H, W, k, d, in_H, in_W, org_y, org_x);
     return run_backward(g, rc, input, weight, offset_y, offset_x, grad_output, grad_input,
-                        grad_weight, grad_offset_y, grad_offset_x, gin_mode, tile_radius, workspace,
-                        workspace_bytes, stream);
+                        grad_weight, grad_offset_y, grad_offset_x, gin_mode, tile_radius, frame_dtype,
+                        workspace, workspace_bytes, stream);
 }
 
 // ---- fused ChronoSynth head ----------------------------------------------------------------
-static int head_setup(Geom &g, HeadArgs &ha, const char *what, const float *const *frames, int T,
+static int head_setup(Geom &g, HeadArgs &ha, const char *what, const void *const *frames, int T,
                       const float *occlusion, int B, int H, int W, int in_H, int in_W, int org_y,
-                      int org_x, int tile_radius, int &R)
+                      int org_x, int frame_dtype, int tile_radius, int &R)
 {
     if (T < 1 || T > kMaxFrames)
         return fail(hipErrorInvalidValue, "%s: T=%d context frames (1..%d supported)", what, T,
@@ -348,47 +429,47 @@ static int head_setup(Geom &g, HeadArgs &ha, const char *what, const float *cons
     }
     ha.occ = occlusion;
     ha.T = T;
+    if (const int e = check_frame_dtype(g, frame_dtype, what)) return e;
     R = pick_radius(tile_radius);
     if (R == 0) R = pick_radius(ARTEMIS_SYNTH_RADIUS_DEFAULT);  // the head has no direct variant
     return 0;
 }
 
-int artemis_synth_head_forward(const float *const *frames, int T, const float *weights,
+int artemis_synth_head_forward(const void *const *frames, int T, const float *weights,
                                const float *offsets_y, const float *offsets_x,
                                const float *occlusion, float *output, int B, int H, int W, int in_H,
-                               int in_W, int org_y, int org_x, int tile_radius, void *stream)
+                               int in_W, int org_y, int org_x, int frame_dtype, int tile_radius,
+                               void *stream)
 {
     Geom g;
     HeadArgs ha;
     int R = 0;
     const int rc = head_setup(g, ha, "artemis_synth_head_forward", frames, T, occlusion, B, H, W, in_H,
-                              in_W, org_y, org_x, tile_radius, R);
+                              in_W, org_y, org_x, frame_dtype, tile_radius, R);
     if (rc > 0) return rc;
     if (rc < 0) return 0;
     if (!weights || !offsets_y || !offsets_x || !output)
         return fail(hipErrorInvalidValue, "artemis_synth_head_forward: NULL tensor pointer");
     hipStream_t st = (hipStream_t)stream;
-    switch (R) {
-    case 2: launch_head_fwd<2>(weights, offsets_y, offsets_x, output, g, ha, st); break;
-    case 4: launch_head_fwd<4>(weights, offsets_y, offsets_x, output, g, ha, st); break;
-    case 8: launch_head_fwd<8>(weights, offsets_y, offsets_x, output, g, ha, st); break;
-    default: launch_head_fwd<16>(weights, offsets_y, offsets_x, output, g, ha, st); break;
-    }
+    if (frame_dtype == ARTEMIS_SYNTH_FRAME_BF16)
+        dispatch_head_fwd<asynth::bf16_t>(R, weights, offsets_y, offsets_x, output, g, ha, st);
+    else
+        dispatch_head_fwd<float>(R, weights, offsets_y, offsets_x, output, g, ha, st);
     return check_launch("artemis_synth_head_forward");
 }
 
-int artemis_synth_head_backward(const float *const *frames, int T, const float *weights,
+int artemis_synth_head_backward(const void *const *frames, int T, const float *weights,
                                 const float *offsets_y, const float *offsets_x,
                                 const float *occlusion, const float *grad_output,
                                 float *grad_weights, float *grad_offsets_y, float *grad_offsets_x,
                                 float *grad_occlusion, int B, int H, int W, int in_H, int in_W,
-                                int org_y, int org_x, int tile_radius, void *stream)
+                                int org_y, int org_x, int frame_dtype, int tile_radius, void *stream)
 {
     Geom g;
     HeadArgs ha;
     int R = 0;
     const int rc = head_setup(g, ha, "artemis_synth_head_backward", frames, T, occlusion, B, H, W,
-                              in_H, in_W, org_y, org_x, tile_radius, R);
+                              in_H, in_W, org_y, org_x, frame_dtype, tile_radius, R);
     if (rc > 0) return rc;
     if (rc < 0) return 0;
     if (!weights || !offsets_y || !offsets_x || !grad_output)
@@ -396,12 +477,12 @@ int artemis_synth_head_backward(const float *const *frames, int T, const float *
     if (!grad_weights && !grad_offsets_y && !grad_offsets_x && !grad_occlusion) return 0;
     ha.gocc = grad_occlusion;
     hipStream_t st = (hipStream_t)stream;
-    switch (R) {
-    case 2: launch_head_bwd<2>(weights, offsets_y, offsets_x, grad_output, grad_weights, grad_offsets_y, grad_offsets_x, g, ha, st); break;
-    case 4: launch_head_bwd<4>(weights, offsets_y, offsets_x, grad_output, grad_weights, grad_offsets_y, grad_offsets_x, g, ha, st); break;
-    case 8: launch_head_bwd<8>(weights, offsets_y, offsets_x, grad_output, grad_weights, grad_offsets_y, grad_offsets_x, g, ha, st); break;
-    default: launch_head_bwd<16>(weights, offsets_y, offsets_x, grad_output, grad_weights, grad_offsets_y, grad_offsets_x, g, ha, st); break;
-    }
+    if (frame_dtype == ARTEMIS_SYNTH_FRAME_BF16)
+        dispatch_head_bwd<asynth::bf16_t>(R, weights, offsets_y, offsets_x, grad_output, grad_weights,
+                                          grad_offsets_y, grad_offsets_x, g, ha, st);
+    else
+        dispatch_head_bwd<float>(R, weights, offsets_y, offsets_x, grad_output, grad_weights,
+                                 grad_offsets_y, grad_offsets_x, g, ha, st);
     return check_launch("artemis_synth_head_backward");
 }
 

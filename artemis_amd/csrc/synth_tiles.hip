@@ -6,6 +6,11 @@
 #ifndef SYNTH_TILE_R
 #error "compile with -DSYNTH_TILE_R=<radius>"
 #endif
+// -DSYNTH_TILE_BF16=1: the bf16-frame instantiations of the same radius (a separate object);
+// gradInput does not read the frame and lives in the fp32 object only.
+#ifndef SYNTH_TILE_BF16
+#define SYNTH_TILE_BF16 0
+#endif
 
 namespace {
 
@@ -36,54 +41,54 @@ struct TileCfg<16> {
 
 namespace asynth {
 
-template <int R>
-void launch_fwd_tiled(const float *in, const float *w, const float *oy, const float *ox, float *out,
+template <int R, class FT>
+void launch_fwd_tiled(const FT *in, const float *w, const float *oy, const float *ox, float *out,
                       const Geom &g, hipStream_t st)
 {
     typedef TileCfg<R> T;
-    hipLaunchKernelGGL((synth_fwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false>),
+    hipLaunchKernelGGL((synth_fwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false, FT>),
                        tile_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, in, w, oy, ox, out,
                        g, HeadArgs{});
 }
 
-template <int R>
-void launch_bwd_tiled(const float *in, const float *w, const float *oy, const float *ox,
+template <int R, class FT>
+void launch_bwd_tiled(const FT *in, const float *w, const float *oy, const float *ox,
                       const float *gout, float *gw, float *goy, float *gox, const Geom &g,
                       hipStream_t st)
 {
     typedef TileCfg<R> T;
     if (gw && goy && gox)
-        hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true, false>),
+        hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true, false, FT>),
                            tile_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, in, w, oy, ox,
                            gout, gw, goy, gox, g, HeadArgs{});
     else
-        hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false, false>),
+        hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false, false, FT>),
                            tile_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, in, w, oy, ox,
                            gout, gw, goy, gox, g, HeadArgs{});
 }
 
-template <int R>
+template <int R, class FT>
 void launch_head_fwd(const float *w, const float *oy, const float *ox, float *out, const Geom &g,
                      const HeadArgs &ha, hipStream_t st)
 {
     typedef TileCfg<R> T;
-    hipLaunchKernelGGL((synth_fwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true>),
-                       tile_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, nullptr, w, oy, ox,
-                       out, g, ha);
+    hipLaunchKernelGGL((synth_fwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true, FT>),
+                       tile_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, (const FT *)nullptr, w, oy,
+                       ox, out, g, ha);
 }
 
-template <int R>
+template <int R, class FT>
 void launch_head_bwd(const float *w, const float *oy, const float *ox, const float *gout, float *gw,
                      float *goy, float *gox, const Geom &g, const HeadArgs &ha, hipStream_t st)
 {
     typedef TileCfg<R> T;
     if (gw && goy && gox)
-        hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true, true>),
-                           tile_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, nullptr, w, oy,
+        hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true, true, FT>),
+                           tile_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, (const FT *)nullptr, w, oy,
                            ox, gout, gw, goy, gox, g, ha);
     else
-        hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false, true>),
-                           tile_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, nullptr, w, oy,
+        hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false, true, FT>),
+                           tile_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, (const FT *)nullptr, w, oy,
                            ox, gout, gw, goy, gox, g, ha);
 }
 
@@ -99,21 +104,31 @@ void launch_gin_tiled(const float *w, const float *oy, const float *ox, const fl
 }
 
 
-template void launch_fwd_tiled<SYNTH_TILE_R>(const float *, const float *, const float *, const float *,
-                                             float *, const Geom &, hipStream_t);
-template void launch_bwd_tiled<SYNTH_TILE_R>(const float *, const float *, const float *, const float *,
-                                             const float *, float *, float *, float *, const Geom &,
-                                             hipStream_t);
-template void launch_head_fwd<SYNTH_TILE_R>(const float *, const float *, const float *, float *,
-                                            const Geom &, const HeadArgs &, hipStream_t);
-template void launch_head_bwd<SYNTH_TILE_R>(const float *, const float *, const float *, const float *,
-                                            float *, float *, float *, const Geom &, const HeadArgs &,
-                                            hipStream_t);
+#if SYNTH_TILE_BF16
+typedef bf16_t frame_t;
+#else
+typedef float frame_t;
+#endif
+
+template void launch_fwd_tiled<SYNTH_TILE_R, frame_t>(const frame_t *, const float *, const float *,
+                                                      const float *, float *, const Geom &,
+                                                      hipStream_t);
+template void launch_bwd_tiled<SYNTH_TILE_R, frame_t>(const frame_t *, const float *, const float *,
+                                                      const float *, const float *, float *, float *,
+                                                      float *, const Geom &, hipStream_t);
+template void launch_head_fwd<SYNTH_TILE_R, frame_t>(const float *, const float *, const float *,
+                                                     float *, const Geom &, const HeadArgs &,
+                                                     hipStream_t);
+template void launch_head_bwd<SYNTH_TILE_R, frame_t>(const float *, const float *, const float *,
+                                                     const float *, float *, float *, float *,
+                                                     const Geom &, const HeadArgs &, hipStream_t);
+#if !SYNTH_TILE_BF16
 template void launch_gin_tiled<SYNTH_TILE_R, false>(const float *, const float *, const float *,
                                                     const float *, float *, unsigned char *,
                                                     const Geom &, int, hipStream_t);
 template void launch_gin_tiled<SYNTH_TILE_R, true>(const float *, const float *, const float *,
                                                    const float *, float *, unsigned char *,
                                                    const Geom &, int, hipStream_t);
+#endif
 
 }  // namespace asynth

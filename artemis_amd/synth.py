@@ -80,11 +80,13 @@ def _dims(input, weight, dilation):
             intInputHeight, intInputWidth)
 
 
-def _check_operands(input, weight, offset_y, offset_x):
+def _check_operands(input, weight, offset_y, offset_x, bf16_frame_ok=False):
     for name, t in (("input", input), ("weight", weight), ("offset_y", offset_y),
                     ("offset_x", offset_x)):
         if t.dim() != 4:
             raise ValueError(f"{name} must be 4-D NCHW, got {tuple(t.shape)}")
+        if name == "input" and bf16_frame_ok and t.dtype == torch.bfloat16:
+            continue
         if t.dtype != torch.float32:
             raise TypeError(f"{name} must be float32 (the reference is fp32 only), got {t.dtype}")
         if t.device != input.device:
@@ -95,18 +97,26 @@ def _check_operands(input, weight, offset_y, offset_x):
         raise ValueError("weight and input batch sizes differ")
 
 
+def _frame_dtype(t):
+    if t.dtype == torch.float32:
+        return _lib.FRAME_F32
+    if t.dtype == torch.bfloat16:
+        return _lib.FRAME_BF16
+    raise TypeError(f"frames must be float32 or bfloat16, got {t.dtype}")
+
+
 def _launch_forward(input, weight, offset_y, offset_x, dilation, geom):
     """geom = (N, C, H, W, k, in_H, in_W, org_y, org_x)"""
     N, C, H, W, k, Hin, Win, oy0, ox0 = geom
     lib = _lib.load()
     with torch.cuda.device(input.device):
         # the kernel writes every element: no need for the reference's new_zeros (:285)
-        output = input.new_empty(N, C, H, W)
+        output = weight.new_empty(N, C, H, W)
         stream = torch.cuda.current_stream().cuda_stream
         _lib.check(lib.artemis_synth_forward_ex(
             _ptr(input), _ptr(weight), _ptr(offset_y), _ptr(offset_x), _ptr(output),
-            N, C, H, W, k, int(dilation), Hin, Win, oy0, ox0, int(options.tile_radius), stream),
-            "artemis_synth_forward")
+            N, C, H, W, k, int(dilation), Hin, Win, oy0, ox0, _frame_dtype(input),
+            int(options.tile_radius), stream), "artemis_synth_forward")
     return output
 
 
@@ -120,10 +130,11 @@ def _launch_backward(need, gradOutput, input, weight, offset_y, offset_x, dilati
 
     lib = _lib.load()
     with torch.cuda.device(input.device):
-        gradInput = input.new_empty(N, C, Hin, Win) if need[0] else None
-        gradWeight = input.new_empty(N, k * k, H, W) if need[1] else None
-        gradOffset_y = input.new_empty(N, k * k, H, W) if need[2] else None
-        gradOffset_x = input.new_empty(N, k * k, H, W) if need[3] else None
+        # gradients are fp32 whatever the frame's dtype
+        gradInput = weight.new_empty(N, C, Hin, Win) if need[0] else None
+        gradWeight = weight.new_empty(N, k * k, H, W) if need[1] else None
+        gradOffset_y = weight.new_empty(N, k * k, H, W) if need[2] else None
+        gradOffset_x = weight.new_empty(N, k * k, H, W) if need[3] else None
 
         deterministic = options.deterministic or torch.are_deterministic_algorithms_enabled()
         mode = _lib.GIN_DETERMINISTIC if deterministic else _lib.GIN_ATOMIC
@@ -138,8 +149,11 @@ def _launch_backward(need, gradOutput, input, weight, offset_y, offset_x, dilati
             _lib.check(lib.artemis_synth_backward_ex(
                 _ptr(input), _ptr(weight), _ptr(offset_y), _ptr(offset_x), _ptr(gradOutput),
                 _ptr(gradInput), _ptr(gradWeight), _ptr(gradOffset_y), _ptr(gradOffset_x),
-                N, C, H, W, k, int(dilation), Hin, Win, oy0, ox0, mode, int(options.tile_radius),
-                _ptr(workspace), ws_bytes, stream), "artemis_synth_backward")
+                N, C, H, W, k, int(dilation), Hin, Win, oy0, ox0, _frame_dtype(input), mode,
+                int(options.tile_radius), _ptr(workspace), ws_bytes, stream),
+                "artemis_synth_backward")
+        if gradInput is not None and gradInput.dtype != input.dtype:
+            gradInput = gradInput.to(input.dtype)   # autograd wants the frame's dtype
     return gradInput, gradWeight, gradOffset_y, gradOffset_x
 
 
@@ -183,7 +197,7 @@ class FunctionSynthFrame(torch.autograd.Function):
     @staticmethod
     def forward(context, frame, weight, offset_y, offset_x, dilation, origin_y, origin_x):
         context.save_for_backward(frame, weight, offset_y, offset_x)
-        _check_operands(frame, weight, offset_y, offset_x)
+        _check_operands(frame, weight, offset_y, offset_x, bf16_frame_ok=True)
         k = int(math.sqrt(weight.size(1)))
         assert k * k == weight.size(1), "weight.size(1) must be a square"
         for t in (frame, weight, offset_y, offset_x):
@@ -261,34 +275,38 @@ class FunctionChronoHead(torch.autograd.Function):
         if tuple(occlusion.shape) != (B, T, H, W):
             raise ValueError("occlusion must be (B, T, H, W)")
         pad = 2 if padded else 0
-        for t in (weights, alphas, betas, occlusion, *frames):
+        for t in (weights, alphas, betas, occlusion):
             if t.dtype != torch.float32:
-                raise TypeError("the fused head is float32 only")
+                raise TypeError("weights, alphas, betas and occlusion must be float32")
+        fdt = _frame_dtype(frames[0])
+        for t in (weights, alphas, betas, occlusion, *frames):
             if t.device != weights.device:
                 raise ValueError("all operands must be on one device")
             assert (t.is_contiguous() == True)
         for f in frames:
             if tuple(f.shape) != (B, 3, H + 2 * pad, W + 2 * pad):
                 raise ValueError(f"frame shape {tuple(f.shape)} does not match the head")
+            if _frame_dtype(f) != fdt:
+                raise TypeError("all frames of a head must have one dtype")
         if not weights.is_cuda:
             raise NotImplementedError()
 
         context.save_for_backward(weights, alphas, betas, occlusion, *frames)
-        context.geom = (B, T, H, W, H + 2 * pad, W + 2 * pad, pad - 2)
+        context.geom = (B, T, H, W, H + 2 * pad, W + 2 * pad, pad - 2, fdt)
         lib = _lib.load()
         with torch.cuda.device(weights.device):
             out = weights.new_empty(B, 3, H, W)
             ptrs = (ctypes.c_void_p * T)(*[f.data_ptr() for f in frames])
             _lib.check(lib.artemis_synth_head_forward(
                 ptrs, T, _ptr(weights), _ptr(alphas), _ptr(betas), _ptr(occlusion), _ptr(out),
-                B, H, W, H + 2 * pad, W + 2 * pad, pad - 2, pad - 2, int(options.tile_radius),
+                B, H, W, H + 2 * pad, W + 2 * pad, pad - 2, pad - 2, fdt, int(options.tile_radius),
                 torch.cuda.current_stream().cuda_stream), "artemis_synth_head_forward")
         return out
 
     @staticmethod
     def backward(context, gradOutput):
         weights, alphas, betas, occlusion, *frames = context.saved_tensors
-        B, T, H, W, Hin, Win, org = context.geom
+        B, T, H, W, Hin, Win, org, fdt = context.geom
         assert (gradOutput.is_contiguous() == True)
         if gradOutput.dtype != torch.float32 or tuple(gradOutput.shape) != (B, 3, H, W):
             raise ValueError("gradOutput must be float32 of the forward output's shape")
@@ -304,7 +322,7 @@ class FunctionChronoHead(torch.autograd.Function):
                 _lib.check(lib.artemis_synth_head_backward(
                     ptrs, T, _ptr(weights), _ptr(alphas), _ptr(betas), _ptr(occlusion),
                     _ptr(gradOutput), _ptr(gw), _ptr(ga), _ptr(gb), _ptr(gocc), B, H, W, Hin, Win,
-                    org, org, int(options.tile_radius),
+                    org, org, fdt, int(options.tile_radius),
                     torch.cuda.current_stream().cuda_stream), "artemis_synth_head_backward")
             # Frame gradients (ArTEMIS never asks for them: its frames are inputs) are not part of
             # the fused kernel: per frame, gradInput of the op for gradOutput * occ_f.

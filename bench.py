@@ -126,11 +126,11 @@ def head_timing(device, radius, sigma, iters=20):
         def fused():
             _lib.check(lib.artemis_synth_head_forward(
                 ptrs, T, w.data_ptr(), a.data_ptr(), b.data_ptr(), occ.data_ptr(), out.data_ptr(),
-                B, H, W, H, W, -2, -2, radius, stream), "head_forward")
+                B, H, W, H, W, -2, -2, 0, radius, stream), "head_forward")
             _lib.check(lib.artemis_synth_head_backward(
                 ptrs, T, w.data_ptr(), a.data_ptr(), b.data_ptr(), occ.data_ptr(), gout.data_ptr(),
                 gw.data_ptr(), ga.data_ptr(), gb.data_ptr(), gocc.data_ptr(), B, H, W, H, W, -2, -2,
-                radius, stream), "head_backward")
+                0, radius, stream), "head_backward")
 
         leaves = [t.clone().requires_grad_(True) for t in (w, a, b, occ)]
 

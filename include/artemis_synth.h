@@ -55,6 +55,13 @@ extern "C" {
 #define ARTEMIS_SYNTH_GIN_ATOMIC 0        /* fp32 atomics across tiles; last-bit run-to-run noise */
 #define ARTEMIS_SYNTH_GIN_DETERMINISTIC 1 /* bit-exact run to run; needs the large workspace */
 
+/* frame_dtype of the *_ex and head entry points: element type of the frame(s).  The reference is
+ * fp32 only (cupy_module/synth.py:9-13 declares float everywhere); bf16 frames (BASELINE configs[4])
+ * are widened exactly to fp32 when staged, all arithmetic and every other tensor stay fp32.  bf16 is
+ * built for k = 5, d = 1, C = 3 (with RADIUS_NONE meaning the default radius). */
+#define ARTEMIS_SYNTH_FRAME_F32 0
+#define ARTEMIS_SYNTH_FRAME_BF16 1
+
 /* Replaces the kernel_Synth_updateOutput launch, cupy_module/synth.py:297-309
  * (kernel text :6-52; called from FunctionSynth.forward :265-313).
  *   output[n,c,y,x] = sum over taps (r,s) of weight[n,r*k+s,y,x] * bilinear(input[n,c], ...)
@@ -91,7 +98,7 @@ size_t artemis_synth_backward_workspace_bytes(int N, int C, int H, int W, int k,
 
 /* ---- explicit frame geometry ------------------------------------------------------------
  * The *_ex entry points are the same kernels with the frame's size and origin passed instead
- * of implied: `input` is (N, C, in_H, in_W) and tap (r, s) of output pixel (y, x) samples around
+ * of implied: `input` is (N, C, in_H, in_W) of frame_dtype (grad_input stays fp32) and tap (r, s) of output pixel (y, x) samples around
  * frame coordinate
  *        ( y + org_y + r*d + trunc(offset_y),  x + org_x + s*d + trunc(offset_x) )
  * with all four corner indices clamped to [0, in_H-1] x [0, in_W-1] as in the reference
@@ -108,17 +115,17 @@ size_t artemis_synth_backward_workspace_bytes(int N, int C, int H, int W, int k,
  *    rows [y0, y1) only (H = y1 - y0), `input` is the whole frame, org_y = y0 (+ the pad origin
  *    above).  grad_input of a strip call covers the whole frame; strips' grad_inputs add.
  * org_y, org_x may be negative; |org| <= 2^24. */
-int artemis_synth_forward_ex(const float *input, const float *weight, const float *offset_y,
+int artemis_synth_forward_ex(const void *input, const float *weight, const float *offset_y,
                              const float *offset_x, float *output, int N, int C, int H, int W, int k,
-                             int d, int in_H, int in_W, int org_y, int org_x, int tile_radius,
-                             void *stream);
+                             int d, int in_H, int in_W, int org_y, int org_x, int frame_dtype,
+                             int tile_radius, void *stream);
 
-int artemis_synth_backward_ex(const float *input, const float *weight, const float *offset_y,
+int artemis_synth_backward_ex(const void *input, const float *weight, const float *offset_y,
                               const float *offset_x, const float *grad_output, float *grad_input,
                               float *grad_weight, float *grad_offset_y, float *grad_offset_x, int N,
                               int C, int H, int W, int k, int d, int in_H, int in_W, int org_y,
-                              int org_x, int gin_mode, int tile_radius, void *workspace,
-                              size_t workspace_bytes, void *stream);
+                              int org_x, int frame_dtype, int gin_mode, int tile_radius,
+                              void *workspace, size_t workspace_bytes, void *stream);
 
 /* Workspace bytes for artemis_synth_backward_ex (grad_input is (N, C, in_H, in_W)). */
 size_t artemis_synth_backward_workspace_bytes_ex(int N, int C, int H, int W, int k, int d, int in_H,
@@ -134,17 +141,18 @@ size_t artemis_synth_backward_workspace_bytes_ex(int N, int C, int H, int W, int
  * The 5-D tensors are read in place (no .contiguous() copies: 600 B/pixel/frame of memcpy in the
  * reference), the per-frame results never leave registers, and the output has the bits of the
  * composition (product rounded to fp32, then added in frame order).
- *   frames      HOST array of T device pointers, each (B, 3, in_H, in_W) fp32; geometry as in the
+ *   frames      HOST array of T device pointers, each (B, 3, in_H, in_W) of frame_dtype; geometry as in the
  *               *_ex entry points (unpadded frames: in_H = H, in_W = W, org = -2; padded: in_H = H+4,
  *               org = 0).  1 <= T <= 8.  The array is read during the call only.
  *   weights / offsets_y / offsets_x   (B, T, 25, H, W) contiguous
  *   occlusion   (B, T, H, W) contiguous          output  (B, 3, H, W)
  * Only the model's configuration k = 5, d = 1, C = 3 (config.py:26-27) is built; tile_radius as
  * above except that RADIUS_NONE means the default (the head has no direct-gather variant). */
-int artemis_synth_head_forward(const float *const *frames, int T, const float *weights,
+int artemis_synth_head_forward(const void *const *frames, int T, const float *weights,
                                const float *offsets_y, const float *offsets_x,
                                const float *occlusion, float *output, int B, int H, int W, int in_H,
-                               int in_W, int org_y, int org_x, int tile_radius, void *stream);
+                               int in_W, int org_y, int org_x, int frame_dtype, int tile_radius,
+                               void *stream);
 
 /* Backward of artemis_synth_head_forward w.r.t. weights, offsets and occlusion (what autograd
  * derives for model/chrono_synth.py:114-129 through FunctionSynth.backward, :316-391, the `occ *`
@@ -153,12 +161,12 @@ int artemis_synth_head_forward(const float *const *frames, int T, const float *w
  * others are fully overwritten.  Frame gradients are not part of this kernel (ArTEMIS's frames are
  * inputs); a caller that needs them uses artemis_synth_backward_ex per frame with
  * grad_output * occlusion. */
-int artemis_synth_head_backward(const float *const *frames, int T, const float *weights,
+int artemis_synth_head_backward(const void *const *frames, int T, const float *weights,
                                 const float *offsets_y, const float *offsets_x,
                                 const float *occlusion, const float *grad_output,
                                 float *grad_weights, float *grad_offsets_y, float *grad_offsets_x,
                                 float *grad_occlusion, int B, int H, int W, int in_H, int in_W,
-                                int org_y, int org_x, int tile_radius, void *stream);
+                                int org_y, int org_x, int frame_dtype, int tile_radius, void *stream);
 
 /* max over both offset tensors of |trunc(offset)| as one int32 written to *out_radius (device
  * memory), enqueued on `stream`: the tile_radius that would serve every tap from LDS.  `count`

@@ -123,17 +123,32 @@ def test_ex_workspace_bytes_and_validation():
     assert f(2, 3, 6, 7, 5, 1, 6, 7, _lib.GIN_ATOMIC) == 256
     # validation returns before any HIP call
     rc = lib.artemis_synth_forward_ex(None, None, None, None, None, 1, 3, 4, 4, 5, 1, 0, 4, 0, 0,
-                                      -1, None)
+                                      0, -1, None)
     assert rc == 1 and "empty frame" in lib.artemis_synth_last_error().decode()
     rc = lib.artemis_synth_forward_ex(None, None, None, None, None, 1, 3, 4, 4, 5, 1, 4, 4,
-                                      1 << 25, 0, -1, None)
+                                      1 << 25, 0, 0, -1, None)
     assert rc == 1 and "origin" in lib.artemis_synth_last_error().decode()
     rc = lib.artemis_synth_forward_ex(None, None, None, None, None, 1, 3, 4, 4, 5, 1, -4, 4, 0, 0,
-                                      -1, None)
+                                      0, -1, None)
     assert rc == 1
     # empty output is a successful no-op whatever the frame
     assert lib.artemis_synth_forward_ex(None, None, None, None, None, 0, 3, 4, 4, 5, 1, 4, 4, 0, 0,
-                                        -1, None) == 0
+                                        0, -1, None) == 0
     rc = lib.artemis_synth_backward_ex(None, None, None, None, None, None, None, None, None, 1, 3,
-                                       4, 4, 5, 1, 4, 4, -2, -2, 7, -1, None, 0, None)
+                                       4, 4, 5, 1, 4, 4, -2, -2, 0, 7, -1, None, 0, None)
     assert rc == 1 and "gin_mode" in lib.artemis_synth_last_error().decode()
+
+
+def test_frame_dtype_validation():
+    lib = _lib.load()
+    # unknown dtype code
+    rc = lib.artemis_synth_forward_ex(None, None, None, None, None, 1, 3, 4, 4, 5, 1, 4, 4, -2, -2,
+                                      5, -1, None)
+    assert rc == 1 and "frame_dtype" in lib.artemis_synth_last_error().decode()
+    # bf16 frames only for the model's k = 5, d = 1, C = 3
+    rc = lib.artemis_synth_forward_ex(None, None, None, None, None, 1, 2, 4, 4, 3, 1, 6, 6, 0, 0,
+                                      _lib.FRAME_BF16, -1, None)
+    assert rc == 1 and "bf16" in lib.artemis_synth_last_error().decode()
+    rc = lib.artemis_synth_backward_ex(None, None, None, None, None, None, None, None, None, 1, 3,
+                                       4, 4, 5, 2, 12, 12, 0, 0, _lib.FRAME_BF16, 0, -1, None, 0, None)
+    assert rc == 1 and "bf16" in lib.artemis_synth_last_error().decode()

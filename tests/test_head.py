@@ -68,7 +68,7 @@ def test_head_abi_validation():
     from artemis_amd import _lib
     lib = _lib.load()
     one = (ctypes.c_void_p * 1)(0)
-    args = (None, None, None, None, None, 1, 4, 4, 4, 4, -2, -2, -1, None)
+    args = (None, None, None, None, None, 1, 4, 4, 4, 4, -2, -2, 0, -1, None)
     assert lib.artemis_synth_head_forward(one, 0, *args) == 1
     assert "context frames" in lib.artemis_synth_last_error().decode()
     assert lib.artemis_synth_head_forward(one, 9, *args) == 1
@@ -77,7 +77,7 @@ def test_head_abi_validation():
     assert "NULL" in lib.artemis_synth_last_error().decode()
     # empty batch: successful no-op before any pointer is looked at
     assert lib.artemis_synth_head_forward(one, 1, None, None, None, None, None, 0, 4, 4, 4, 4, -2,
-                                          -2, -1, None) == 0
+                                          -2, 0, -1, None) == 0
 
 
 def test_head_host_contract_on_cpu():

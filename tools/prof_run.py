@@ -64,11 +64,11 @@ def main():
         for _ in range(a.iters):
             _lib.check(lib.artemis_synth_head_forward(
                 ptrs, T, w.data_ptr(), al.data_ptr(), be.data_ptr(), occ.data_ptr(), out.data_ptr(),
-                1, H, W, H + 4, W + 4, 0, 0, a.radius, st), "head fwd")
+                1, H, W, H + 4, W + 4, 0, 0, 0, a.radius, st), "head fwd")
             _lib.check(lib.artemis_synth_head_backward(
                 ptrs, T, w.data_ptr(), al.data_ptr(), be.data_ptr(), occ.data_ptr(), gout.data_ptr(),
                 gw.data_ptr(), ga.data_ptr(), gb.data_ptr(), gocc.data_ptr(), 1, H, W, H + 4, W + 4,
-                0, 0, a.radius, st), "head bwd")
+                0, 0, 0, a.radius, st), "head bwd")
     torch.cuda.synchronize()
 
 
