@@ -381,7 +381,19 @@ __global__ __launch_bounds__(256) void stream_tapmajor_v(const float *__restrict
     __shared__ float dummy[LDSB / 4];
     if (LDSB > 4 && threadIdx.x == 999) dummy[threadIdx.y] = 0;
     constexpr int TH = 4 * RW;
-    const int tx0 = blockIdx.x * 64 * VEC, ty0 = blockIdx.y * TH;
+    int tx0, ty0;
+    if (NT & 4) {  // XCD-aware banded tile order (1-D grid padded to a multiple of 8)
+        const unsigned tiles_x = (unsigned)(W + 64 * VEC - 1) / (64 * VEC), tiles_y = (unsigned)(H + TH - 1) / TH;
+        const unsigned nb = tiles_x * tiles_y, per = (nb + 7) / 8;
+        const unsigned t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        if (t >= nb) return;
+        const unsigned ty = t / tiles_x;
+        tx0 = (int)(t - ty * tiles_x) * 64 * VEC;
+        ty0 = (int)ty * TH;
+    } else {
+        tx0 = blockIdx.x * 64 * VEC;
+        ty0 = blockIdx.y * TH;
+    }
     const int wy = __builtin_amdgcn_readfirstlane(threadIdx.y);
     const unsigned x = tx0 + threadIdx.x * VEC;
     if ((int)x >= W) return;  // W % VEC == 0 assumed
@@ -423,7 +435,14 @@ __global__ __launch_bounds__(256) void stream_tapmajor_v(const float *__restrict
         }
         if (!BWD) {
 #pragma unroll
-            for (int i = 0; i < 3 * RW; ++i) asm volatile("" : "+v"(acc[i]));
+            for (int i = 0; i < 3 * RW; ++i) {
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) {
+                    float t = acc[i][c];
+                    asm volatile("" : "+v"(t));
+                    acc[i][c] = t;
+                }
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -438,10 +457,112 @@ __global__ __launch_bounds__(256) void stream_tapmajor_v(const float *__restrict
         }
     }
 }
+// as stream_tapmajor_v, but only 32 lanes per row (tile stays 64 pixels wide with VEC = 2): a wave
+// instruction covers 2 rows x 256 B.  Separates "wider contiguous pieces" from "wider accesses".
+// tap-major with a lane owning VEC consecutive pixels: a wave covers 64*VEC pixels of RW rows
+// (dwordx2/x4 accesses: 512 B / 1 KB contiguous per wave instruction instead of 256 B), same
+// pixels per wave (64 * VEC * RW) as the scalar layout with ROWS = VEC * RW.
+template <int LDSB, int VEC, int RW, bool BWD, int NT>
+__global__ __launch_bounds__(256) void stream_tapmajor_h(const float *__restrict__ w, const float *__restrict__ oy,
+                                                  const float *__restrict__ ox, float *__restrict__ gw,
+                                                  float *__restrict__ ga, float *__restrict__ gb,
+                                                  int H, int W)
+{
+    typedef float vecf __attribute__((ext_vector_type(VEC)));
+    __shared__ float dummy[LDSB / 4];
+    if (LDSB > 4 && threadIdx.x == 999) dummy[threadIdx.y] = 0;
+    constexpr int XW = 64 / VEC, SUB = VEC, TH = 4 * RW * SUB;
+    int tx0, ty0;
+    if (NT & 4) {  // XCD-aware banded tile order (1-D grid padded to a multiple of 8)
+        const unsigned tiles_x = (unsigned)(W + 63) / 64, tiles_y = (unsigned)(H + TH - 1) / TH;
+        const unsigned nb = tiles_x * tiles_y, per = (nb + 7) / 8;
+        const unsigned t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        if (t >= nb) return;
+        const unsigned ty = t / tiles_x;
+        tx0 = (int)(t - ty * tiles_x) * 64;
+        ty0 = (int)ty * TH;
+    } else {
+        tx0 = blockIdx.x * 64;
+        ty0 = blockIdx.y * TH;
+    }
+    const int wy = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const unsigned x = tx0 + (threadIdx.x % XW) * VEC;
+    const int sub = threadIdx.x / XW;
+    if ((int)x >= W) return;  // W % VEC == 0 assumed
+    const size_t plane = (size_t)H * W;
+    vecf buf[2][3 * RW];
+    vecf acc[3 * RW];
+#pragma unroll
+    for (int i = 0; i < 3 * RW; ++i) acc[i] = 0;
+    auto issue = [&](int t, vecf *dst) {
+#pragma unroll
+        for (int j = 0; j < RW; ++j) {
+            const int y = min(ty0 + wy * SUB + sub + 4 * SUB * j, H - 1);
+            const size_t o = (size_t)y * W + (size_t)t * plane;
+            dst[3 * j] = __builtin_nontemporal_load((const vecf *)(w + o + x));
+            dst[3 * j + 1] = __builtin_nontemporal_load((const vecf *)(oy + o + x));
+            dst[3 * j + 2] = __builtin_nontemporal_load((const vecf *)(ox + o + x));
+        }
+    };
+    issue(0, buf[0]);
+#pragma unroll
+    for (int t = 0; t < 25; ++t) {
+        if (t + 1 < 25) issue(t + 1, buf[(t + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        vecf *c = buf[t & 1];
+#pragma unroll
+        for (int j = 0; j < RW; ++j) {
+            const int y = ty0 + wy * SUB + sub + 4 * SUB * j;
+            if (BWD) {
+                if (y < H) {
+                    const size_t o = (size_t)y * W + (size_t)t * plane;
+                    const vecf v0 = c[3 * j] * 1.5f, v1 = c[3 * j + 1] + c[3 * j], v2 = c[3 * j + 2] - c[3 * j];
+                    __builtin_nontemporal_store(v0, (vecf *)(gw + o + x));
+                    __builtin_nontemporal_store(v1, (vecf *)(ga + o + x));
+                    __builtin_nontemporal_store(v2, (vecf *)(gb + o + x));
+                }
+            } else {
+                acc[3 * j] += c[3 * j]; acc[3 * j + 1] += c[3 * j + 1]; acc[3 * j + 2] += c[3 * j + 2];
+            }
+        }
+        if (!BWD) {
+#pragma unroll
+            for (int i = 0; i < 3 * RW; ++i) {
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) {
+                    float t = acc[i][c];
+                    asm volatile("" : "+v"(t));
+                    acc[i][c] = t;
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!BWD) {
+#pragma unroll
+        for (int j = 0; j < RW; ++j) {
+            const int y = ty0 + wy * SUB + sub + 4 * SUB * j;
+            if (y < H) {
+                float *orow = gw + (size_t)y * W;
+                *(vecf *)(orow + x) = acc[3 * j]; *(vecf *)(orow + plane + x) = acc[3 * j + 1]; *(vecf *)(orow + 2 * plane + x) = acc[3 * j + 2];
+            }
+        }
+    }
+}
 template <int LDSB, int VEC, int RW, bool BWD, int NT>
 static void ltmv(const float *w, const float *oy, const float *ox, float *gw, float *ga, float *gb, int H, int W, hipStream_t st)
 {
-    hipLaunchKernelGGL((stream_tapmajor_v<LDSB, VEC, RW, BWD, NT>), dim3((W + 64 * VEC - 1) / (64 * VEC), (H + 4 * RW - 1) / (4 * RW)), dim3(64, 4), 0, st, w, oy, ox, gw, ga, gb, H, W);
+    const unsigned tiles_x = (W + 64 * VEC - 1) / (64 * VEC), tiles_y = (H + 4 * RW - 1) / (4 * RW);
+    const dim3 grid = (NT & 4) ? dim3(((tiles_x * tiles_y + 7) / 8) * 8) : dim3(tiles_x, tiles_y);
+    hipLaunchKernelGGL((stream_tapmajor_v<LDSB, VEC, RW, BWD, NT>), grid, dim3(64, 4), 0, st, w, oy, ox, gw, ga, gb, H, W);
+}
+
+template <int LDSB, int VEC, int RW, bool BWD, int NT>
+static void ltmh(const float *w, const float *oy, const float *ox, float *gw, float *ga, float *gb, int H, int W, hipStream_t st)
+{
+    const unsigned tiles_x = (W + 63) / 64, tiles_y = (H + 4 * RW * VEC - 1) / (4 * RW * VEC);
+    const dim3 grid = (NT & 4) ? dim3(((tiles_x * tiles_y + 7) / 8) * 8) : dim3(tiles_x, tiles_y);
+    hipLaunchKernelGGL((stream_tapmajor_h<LDSB, VEC, RW, BWD, NT>), grid, dim3(64, 4), 0, st, w, oy, ox, gw, ga, gb, H, W);
 }
 
 // persistent tap-major with a soft global pace-maker: a wave does not start tap t+1 until every
@@ -593,6 +714,17 @@ extern "C" int exp_runb(int variant, const float *w, const float *oy, const floa
     case 56: lts<70000, 32, false, 2>(512, w, oy, ox, gw, ga, gb, H, W, st); break;
     case 57: lts<36000, 32, true, 2>(1024, w, oy, ox, gw, ga, gb, H, W, st); break;
     case 58: lts<36000, 32, true, 0>(1024, w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 80: ltmh<54000, 2, 4, true, 3>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 81: ltmh<54000, 2, 4, true, 7>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 82: ltmh<54000, 4, 2, true, 3>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 83: ltmh<54000, 2, 4, false, 3>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 70: ltmv<54000, 1, 8, true, 7>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 71: ltmv<54000, 2, 4, true, 7>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 72: ltmv<54000, 4, 2, true, 7>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 73: ltmv<54000, 1, 8, false, 7>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 74: ltmv<54000, 2, 4, false, 7>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 75: ltmv<54000, 2, 8, true, 7>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 76: ltmv<54000, 2, 2, true, 7>(w, oy, ox, gw, ga, gb, H, W, st); break;
     case 60: ltmv<54000, 2, 4, true, 3>(w, oy, ox, gw, ga, gb, H, W, st); break;
     case 61: ltmv<54000, 4, 2, true, 3>(w, oy, ox, gw, ga, gb, H, W, st); break;
     case 62: ltmv<54000, 2, 4, false, 3>(w, oy, ox, gw, ga, gb, H, W, st); break;
