@@ -342,10 +342,16 @@ static int run_backward(const Geom &g, int rc, const void *input_any, const floa
         if (e != hipSuccess) return fail((int)e, "hipMemsetAsync: %s", hipGetErrorString(e));
         if (need) {  // maxima for the fixed-point scale
             const size_t wcount = (size_t)N * k * k * H * W, gcount = (size_t)N * C * H * W;
-            hipLaunchKernelGGL(absmax_kernel, dim3(reduce_blocks(wcount)), dim3(256), 0, st, weight,
-                               wcount, (unsigned *)ws);
-            hipLaunchKernelGGL(absmax_kernel, dim3(reduce_blocks(gcount)), dim3(256), 0, st,
-                               grad_output, gcount, (unsigned *)ws + 1);
+            // one launch for both maxima; ~16 KB of 16-byte loads per block and pass
+            const int vec = (((uintptr_t)weight | (uintptr_t)grad_output) & 15) == 0;
+            const size_t per_block = 256 * 4 * 4 * 4;  // elements a block covers per unrolled pass
+            auto blocks_for = [&](size_t n) {
+                const size_t b = (n + per_block - 1) / per_block;
+                return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+            };
+            const unsigned ba = blocks_for(wcount), bb = blocks_for(gcount);
+            hipLaunchKernelGGL(absmax2_kernel, dim3(ba + bb), dim3(256), 0, st, weight, wcount,
+                               grad_output, gcount, ba, vec, (unsigned *)ws);
         }
         if (Rg > 0) {
             switch (Rg * 2 + (fixed ? 1 : 0)) {
