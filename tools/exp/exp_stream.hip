@@ -407,9 +407,15 @@ __global__ __launch_bounds__(256) void stream_tapmajor_v(const float *__restrict
         for (int j = 0; j < RW; ++j) {
             const int y = min(ty0 + wy + 4 * j, H - 1);
             const size_t o = (size_t)y * W + (size_t)t * plane;
-            dst[3 * j] = __builtin_nontemporal_load((const vecf *)(w + o + x));
-            dst[3 * j + 1] = __builtin_nontemporal_load((const vecf *)(oy + o + x));
-            dst[3 * j + 2] = __builtin_nontemporal_load((const vecf *)(ox + o + x));
+            if (NT & 8) {  // write-only experiment: no loads
+                dst[3 * j] = (float)(o & 1023);
+                dst[3 * j + 1] = (float)t;
+                dst[3 * j + 2] = (float)x;
+            } else {
+                dst[3 * j] = __builtin_nontemporal_load((const vecf *)(w + o + x));
+                dst[3 * j + 1] = __builtin_nontemporal_load((const vecf *)(oy + o + x));
+                dst[3 * j + 2] = __builtin_nontemporal_load((const vecf *)(ox + o + x));
+            }
         }
     };
     issue(0, buf[0]);
@@ -714,6 +720,9 @@ extern "C" int exp_runb(int variant, const float *w, const float *oy, const floa
     case 56: lts<70000, 32, false, 2>(512, w, oy, ox, gw, ga, gb, H, W, st); break;
     case 57: lts<36000, 32, true, 2>(1024, w, oy, ox, gw, ga, gb, H, W, st); break;
     case 58: lts<36000, 32, true, 0>(1024, w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 90: ltmv<54000, 1, 8, true, 11>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 91: ltmv<54000, 2, 4, true, 11>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 92: ltmv<54000, 4, 2, true, 11>(w, oy, ox, gw, ga, gb, H, W, st); break;
     case 80: ltmh<54000, 2, 4, true, 3>(w, oy, ox, gw, ga, gb, H, W, st); break;
     case 81: ltmh<54000, 2, 4, true, 7>(w, oy, ox, gw, ga, gb, H, W, st); break;
     case 82: ltmh<54000, 4, 2, true, 3>(w, oy, ox, gw, ga, gb, H, W, st); break;
