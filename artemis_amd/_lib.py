@@ -34,6 +34,7 @@ SIGNATURES = {
     "artemis_synth_head_forward": (_i, [_vp, _i] + [_vp] * 5 + [_i] * 9 + [_vp]),
     "artemis_synth_head_backward": (_i, [_vp, _i] + [_vp] * 9 + [_i] * 9 + [_vp]),
     "artemis_synth_offset_radius": (_i, [_vp, _vp, ctypes.c_size_t, _vp, _vp]),
+    "artemis_synth_set_small_grid_tiles": (ctypes.c_longlong, [ctypes.c_longlong]),
     "artemis_synth_version": (ctypes.c_char_p, []),
     "artemis_synth_last_error": (ctypes.c_char_p, []),
 }

@@ -74,6 +74,10 @@ template <int R, bool FIXED>
 void launch_gin_tiled(const float *w, const float *oy, const float *ox, const float *gout, float *gin,
                       unsigned char *ws, const Geom &g, int bits, hipStream_t st);
 
+// Grids with fewer 64 x 32 tiles than this run with 64 x 8 tiles (synth_tiles.hip); process-wide
+// tuning knob, set through artemis_synth_set_small_grid_tiles (defined in synth_kernels.hip).
+long long small_grid_tiles();
+
 inline dim3 pixel_grid(const Geom &g, int rows_per_block)
 {
     return dim3((unsigned)((g.W + 63) / 64), (unsigned)((g.H + rows_per_block - 1) / rows_per_block),

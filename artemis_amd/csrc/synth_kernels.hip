@@ -5,7 +5,14 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "synth_device.hpp"
+
+namespace asynth {
+static std::atomic<long long> g_small_grid_tiles{768};
+long long small_grid_tiles() { return g_small_grid_tiles.load(std::memory_order_relaxed); }
+}  // namespace asynth
 
 namespace {
 
@@ -490,6 +497,12 @@ int artemis_synth_head_backward(const void *const *frames, int T, const float *w
         dispatch_head_bwd<float>(R, weights, offsets_y, offsets_x, grad_output, grad_weights,
                                  grad_offsets_y, grad_offsets_x, g, ha, st);
     return check_launch("artemis_synth_head_backward");
+}
+
+long long artemis_synth_set_small_grid_tiles(long long tiles)
+{
+    if (tiles < 0) return asynth::g_small_grid_tiles.load(std::memory_order_relaxed);
+    return asynth::g_small_grid_tiles.exchange(tiles, std::memory_order_relaxed);
 }
 
 int artemis_synth_offset_radius(const float *offset_y, const float *offset_x, size_t count,

@@ -37,6 +37,63 @@ struct TileCfg<16> {
     static constexpr int WAVES = 8, ROWS = 4, OCC = 2;
 };
 
+// Small grids: a problem with fewer than small_grid_tiles() (default 768) tiles of 64 x 32 pixels (the 64^2 and 128^2
+// heads of a small-batch training step, BASELINE configs[0] and [2]) cannot fill 256 CUs and is
+// bound by one workgroup's serial time.  It runs with 64 x 8 tiles instead (4 waves x 2 rows):
+// 4x the workgroups, each a quarter of the work.  Same per-pixel arithmetic, same bits.
+
+struct SmallCfg {
+    static constexpr int WAVES = 4, ROWS = 2, OCC = 2;
+};
+
+// The backward (more work per tile, more sensitive to a ragged last round of workgroups) switches
+// at the knob, the forward at a quarter of it: measured crossovers on 256 CUs are ~770 and ~160
+// tiles (tools/head_sweep.py).
+template <class T>
+bool small_grid(const asynth::Geom &g, bool backward)
+{
+    const long long tiles = (long long)((g.W + 63) / 64) * ((g.H + T::WAVES * T::ROWS - 1) / (T::WAVES * T::ROWS)) * g.N;
+    const long long knob = asynth::small_grid_tiles();
+    return tiles < (backward ? knob : (knob + 3) / 4);
+}
+
+template <int R, class T, class FT>
+void fwd_cfg(bool head, const FT *in, const float *w, const float *oy, const float *ox, float *out,
+             const asynth::Geom &g, const asynth::HeadArgs &ha, hipStream_t st)
+{
+    const dim3 grid = asynth::tile_grid(g, T::WAVES * T::ROWS), block(64, T::WAVES);
+    if (head)
+        hipLaunchKernelGGL((synth_fwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true, FT>), grid, block, 0, st,
+                           in, w, oy, ox, out, g, ha);
+    else
+        hipLaunchKernelGGL((synth_fwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false, FT>), grid, block, 0,
+                           st, in, w, oy, ox, out, g, ha);
+}
+
+template <int R, class T, class FT>
+void bwd_cfg(bool head, const FT *in, const float *w, const float *oy, const float *ox,
+             const float *gout, float *gw, float *goy, float *gox, const asynth::Geom &g,
+             const asynth::HeadArgs &ha, hipStream_t st)
+{
+    const dim3 grid = asynth::tile_grid(g, T::WAVES * T::ROWS), block(64, T::WAVES);
+    const bool all = gw && goy && gox;
+    if (head) {
+        if (all)
+            hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true, true, FT>), grid,
+                               block, 0, st, in, w, oy, ox, gout, gw, goy, gox, g, ha);
+        else
+            hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false, true, FT>), grid,
+                               block, 0, st, in, w, oy, ox, gout, gw, goy, gox, g, ha);
+    } else {
+        if (all)
+            hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true, false, FT>), grid,
+                               block, 0, st, in, w, oy, ox, gout, gw, goy, gox, g, ha);
+        else
+            hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false, false, FT>), grid,
+                               block, 0, st, in, w, oy, ox, gout, gw, goy, gox, g, ha);
+    }
+}
+
 }  // namespace
 
 namespace asynth {
@@ -45,10 +102,8 @@ template <int R, class FT>
 void launch_fwd_tiled(const FT *in, const float *w, const float *oy, const float *ox, float *out,
                       const Geom &g, hipStream_t st)
 {
-    typedef TileCfg<R> T;
-    hipLaunchKernelGGL((synth_fwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false, FT>),
-                       tile_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, in, w, oy, ox, out,
-                       g, HeadArgs{});
+    if (small_grid<TileCfg<R>>(g, false)) fwd_cfg<R, SmallCfg, FT>(false, in, w, oy, ox, out, g, HeadArgs{}, st);
+    else fwd_cfg<R, TileCfg<R>, FT>(false, in, w, oy, ox, out, g, HeadArgs{}, st);
 }
 
 template <int R, class FT>
@@ -56,40 +111,28 @@ void launch_bwd_tiled(const FT *in, const float *w, const float *oy, const float
                       const float *gout, float *gw, float *goy, float *gox, const Geom &g,
                       hipStream_t st)
 {
-    typedef TileCfg<R> T;
-    if (gw && goy && gox)
-        hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true, false, FT>),
-                           tile_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, in, w, oy, ox,
-                           gout, gw, goy, gox, g, HeadArgs{});
+    if (small_grid<TileCfg<R>>(g, true))
+        bwd_cfg<R, SmallCfg, FT>(false, in, w, oy, ox, gout, gw, goy, gox, g, HeadArgs{}, st);
     else
-        hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false, false, FT>),
-                           tile_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, in, w, oy, ox,
-                           gout, gw, goy, gox, g, HeadArgs{});
+        bwd_cfg<R, TileCfg<R>, FT>(false, in, w, oy, ox, gout, gw, goy, gox, g, HeadArgs{}, st);
 }
 
 template <int R, class FT>
 void launch_head_fwd(const float *w, const float *oy, const float *ox, float *out, const Geom &g,
                      const HeadArgs &ha, hipStream_t st)
 {
-    typedef TileCfg<R> T;
-    hipLaunchKernelGGL((synth_fwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true, FT>),
-                       tile_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, (const FT *)nullptr, w, oy,
-                       ox, out, g, ha);
+    if (small_grid<TileCfg<R>>(g, false)) fwd_cfg<R, SmallCfg, FT>(true, (const FT *)nullptr, w, oy, ox, out, g, ha, st);
+    else fwd_cfg<R, TileCfg<R>, FT>(true, (const FT *)nullptr, w, oy, ox, out, g, ha, st);
 }
 
 template <int R, class FT>
 void launch_head_bwd(const float *w, const float *oy, const float *ox, const float *gout, float *gw,
                      float *goy, float *gox, const Geom &g, const HeadArgs &ha, hipStream_t st)
 {
-    typedef TileCfg<R> T;
-    if (gw && goy && gox)
-        hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true, true, FT>),
-                           tile_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, (const FT *)nullptr, w, oy,
-                           ox, gout, gw, goy, gox, g, ha);
+    if (small_grid<TileCfg<R>>(g, true))
+        bwd_cfg<R, SmallCfg, FT>(true, (const FT *)nullptr, w, oy, ox, gout, gw, goy, gox, g, ha, st);
     else
-        hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false, true, FT>),
-                           tile_grid(g, T::WAVES * T::ROWS), dim3(64, T::WAVES), 0, st, (const FT *)nullptr, w, oy,
-                           ox, gout, gw, goy, gox, g, ha);
+        bwd_cfg<R, TileCfg<R>, FT>(true, (const FT *)nullptr, w, oy, ox, gout, gw, goy, gox, g, ha, st);
 }
 
 // gradInput tiles: 64 x 16 pixels, 64-bit accumulators (3 x 29 x 77 x 8 B = 53.6 KB at R = 4,

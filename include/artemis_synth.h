@@ -175,6 +175,14 @@ int artemis_synth_head_backward(const void *const *frames, int T, const float *w
 int artemis_synth_offset_radius(const float *offset_y, const float *offset_x, size_t count,
                                 int *out_radius, void *stream);
 
+/* Process-wide tuning knob (the only mutable state of the library, one atomic integer): problems
+ * with fewer than `tiles` workgroup tiles of 64 x 32 pixels (N * ceil(W/64) * ceil(H/32)) run with
+ * 64 x 8 tiles so that small grids (the 64^2 / 128^2 heads of a small-batch training step) still
+ * spread over the CUs (the forward switches at a quarter of that count).  Default 768.  0 = never, a huge value = always; results are bit-identical
+ * either way.  Returns the previous value; a negative argument only queries.  No reference
+ * counterpart. */
+long long artemis_synth_set_small_grid_tiles(long long tiles);
+
 /* Library identification: "artemis_synth <abi> gfx950 ..." (static storage). */
 const char *artemis_synth_version(void);
 

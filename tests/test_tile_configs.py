@@ -1,0 +1,114 @@
+"""The two workgroup tile shapes (64 x 32 for full grids, 64 x 8 for small grids, chosen by
+artemis_synth_set_small_grid_tiles) compute the same bits; the 64 x 32 kernels, which the small
+test shapes would otherwise never reach, are held to the oracle here."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import make_operands
+from test_head import head_operands
+
+pytestmark = pytest.mark.gpu
+
+FWD_RTOL = 1e-5
+BWD_RTOL = 1e-4
+ALWAYS_BIG, ALWAYS_SMALL = 0, 1 << 40
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import artemis_amd
+    artemis_amd._lib.load()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture
+def knob():
+    from artemis_amd import _lib
+    lib = _lib.load()
+    old = lib.artemis_synth_set_small_grid_tiles(-1)
+    yield lib.artemis_synth_set_small_grid_tiles
+    lib.artemis_synth_set_small_grid_tiles(old)
+
+
+def close(actual, desired, rtol, what="", floor=1e-30):
+    actual = actual.detach().cpu().numpy() if torch.is_tensor(actual) else actual
+    scale = float(np.abs(desired).max()) if desired.size else 0.0
+    np.testing.assert_allclose(actual, desired, rtol=rtol, atol=rtol * max(scale, floor), err_msg=what)
+
+
+def run_op(dev, ops, gout, radius, det):
+    import artemis_amd
+    t = [torch.from_numpy(a).to(dev).requires_grad_(True) for a in ops]
+    with artemis_amd.synth_options(tile_radius=radius, deterministic=det):
+        out = artemis_amd.FunctionSynth.apply(*t, 1)
+        out.backward(torch.from_numpy(gout).to(dev))
+    torch.cuda.synchronize()
+    return out.detach(), [x.grad for x in t]
+
+
+def test_knob_roundtrip(knob):
+    assert knob(-1) == 768          # the default
+    assert knob(5) == 768 and knob(-1) == 5
+    assert knob(768) == 5
+
+
+@pytest.mark.parametrize("radius", [-1, 2, 8])
+@pytest.mark.parametrize("cfg", [(2, 33, 70, "gauss1"), (1, 64, 129, "gauss4"), (3, 1, 1, "gauss1"),
+                                 (1, 40, 200, "clamp40"), (1, 9, 64, "integer")])
+def test_both_tile_shapes_same_bits_and_oracle(dev, oracle, knob, cfg, radius):
+    N, H, W, regime = cfg
+    inp, w, oy, ox, gout = make_operands(N, 3, H, W, 5, 1, regime, seed=H * 7 + W)
+    knob(ALWAYS_BIG)
+    out_b, g_b = run_op(dev, (inp, w, oy, ox), gout, radius, det=True)
+    knob(ALWAYS_SMALL)
+    out_s, g_s = run_op(dev, (inp, w, oy, ox), gout, radius, det=True)
+    assert torch.equal(out_b, out_s)
+    for a, b in zip(g_b, g_s):
+        assert torch.equal(a, b)       # incl. deterministic gradInput
+    close(out_b, oracle.forward(inp, w, oy, ox, 1), FWD_RTOL, "output")
+    ref = oracle.backward(gout, inp, w, oy, ox, 1)
+    for g, r, name in zip(g_b, ref, ("grad_input", "grad_weight", "grad_offset_y", "grad_offset_x")):
+        close(g, r, BWD_RTOL, name)
+
+
+@pytest.mark.parametrize("radius", [-1, 4])
+def test_head_both_tile_shapes(dev, oracle, knob, radius):
+    import artemis_amd
+    frames, w, a, b, occ, gout = head_operands(2, 4, 37, 90, "gauss4", seed=17)
+
+    def run():
+        t = [torch.from_numpy(x).to(dev).requires_grad_(True) for x in (w, a, b, occ)]
+        with artemis_amd.synth_options(tile_radius=radius):
+            out = artemis_amd.chrono_head([torch.from_numpy(f).to(dev) for f in frames], *t)
+            out.backward(torch.from_numpy(gout).to(dev))
+        torch.cuda.synchronize()
+        return out.detach(), [x.grad for x in t]
+
+    knob(ALWAYS_BIG)
+    out_b, g_b = run()
+    knob(ALWAYS_SMALL)
+    out_s, g_s = run()
+    assert torch.equal(out_b, out_s)
+    for x, y in zip(g_b, g_s):
+        assert torch.equal(x, y)
+    ref, _ = oracle.head_forward(frames, w, a, b, occ, 1)
+    close(out_b, ref, FWD_RTOL, "framet")
+    for g, r in zip(g_b, oracle.head_backward(gout, frames, w, a, b, occ, 1)):
+        close(g, r, BWD_RTOL, floor=float(np.abs(gout).max() * np.abs(w).max()))
+
+
+def test_full_size_small_tiles_equal_big(dev, knob):
+    import artemis_amd
+    g = torch.Generator(device=dev).manual_seed(2)
+    H, W = 1080, 1920
+    frame = torch.rand(1, 3, H, W, device=dev, generator=g)
+    w = torch.softmax(torch.randn(1, 25, H, W, device=dev, generator=g), 1)
+    oy = torch.randn(1, 25, H, W, device=dev, generator=g) * 2
+    ox = torch.randn(1, 25, H, W, device=dev, generator=g) * 2
+    knob(ALWAYS_BIG)
+    a = artemis_amd.synth_unpadded(frame, w, oy, ox, 1)
+    knob(ALWAYS_SMALL)
+    b = artemis_amd.synth_unpadded(frame, w, oy, ox, 1)
+    assert torch.equal(a, b)

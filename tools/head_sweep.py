@@ -19,6 +19,8 @@ def main():
     for a in sys.argv[1:]:
         if a.startswith("--radius="):
             radius = int(a.split("=")[1])
+        if a.startswith("--small="):   # small-grid threshold (tiles); default: the library's
+            _lib.load().artemis_synth_set_small_grid_tiles(int(a.split("=")[1]))
     dev = torch.device("cuda:0")
     lib = _lib.load()
     st = torch.cuda.current_stream().cuda_stream
