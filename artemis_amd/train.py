@@ -1,0 +1,111 @@
+"""A Lightning-free training step around the synthesis head: ChronoSynth (this package's
+restatement, fused head op) + L1 loss + Adamax + MultiStepLR, one process per GPU with
+``torch.distributed`` -- the pieces of the reference's ``main.py`` that touch the hot path
+(``main.py:45`` Adamax, ``:93`` MultiStepLR(gamma 0.5), ``loss.py:9`` L1; Lightning DDP ``:135``).
+
+The op itself needs no collective: the batch is sharded over ranks (``sharding.shard_batch``) and
+the only exchange of a step is DDP's gradient all-reduce of the module's parameters (RCCL over
+xGMI with backend ``nccl``; ``gloo`` works for rehearsals).  The encoder/decoder that produce the
+features upstream are stock PyTorch ops and are stood in for by given feature tensors.
+
+    torchrun --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m artemis_amd.train --steps 5
+"""
+from __future__ import annotations
+
+import argparse
+import os
+
+import torch
+import torch.nn as nn
+
+from .device import add_device_argument, select_device
+from .model import ChronoSynth
+from .sharding import shard_bounds
+
+
+def synthetic_batch(batch, num_features, size, seed, device):
+    """features (B, F, 4, H/2, W/2), 4 frames (B, 3, H, W), ground truth (B, 3, H, W), times (B,)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    H, W = size
+    feats = torch.randn(batch, num_features, 4, (H + 1) // 2, (W + 1) // 2, generator=g)
+    frames = [torch.rand(batch, 3, H, W, generator=g) for _ in range(4)]
+    gt = torch.rand(batch, 3, H, W, generator=g)
+    t = torch.rand(batch, generator=g)
+    return (feats.to(device), [f.to(device) for f in frames], gt.to(device), t.to(device))
+
+
+class HeadTrainer:
+    """One ChronoSynth head under Adamax + MultiStepLR, data-parallel over the process group."""
+
+    def __init__(self, device, num_features=64, lr=2e-4, betas=(0.9, 0.999), milestones=(100, 150),
+                 seed=103, fused=True):
+        torch.manual_seed(seed)          # config.py:62; same init on every rank
+        self.device = device
+        self.module = ChronoSynth(4, num_features, 5, 1, apply_softmax=True, fused=fused).to(device)
+        self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+        self.rank = torch.distributed.get_rank() if self.world > 1 else 0
+        self.model = self.module
+        if self.world > 1:
+            self.model = nn.parallel.DistributedDataParallel(
+                self.module, device_ids=[device.index], broadcast_buffers=False)
+        self.optimizer = torch.optim.Adamax(self.module.parameters(), lr=lr, betas=betas)
+        self.scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, list(milestones), gamma=0.5)
+        self.loss = nn.L1Loss(reduction="mean")
+
+    def shard(self, batch):
+        """This rank's slice of a global batch (features, frames, gt, times)."""
+        feats, frames, gt, t = batch
+        b, e = shard_bounds(feats.size(0), self.rank, self.world)
+        return feats[b:e], [f[b:e] for f in frames], gt[b:e], t[b:e]
+
+    def step(self, global_batch):
+        feats, frames, gt, t = self.shard(global_batch)
+        self.optimizer.zero_grad(set_to_none=True)
+        out = self.model(feats, frames, tuple(gt.shape[-2:]), t)
+        loss = self.loss(out, gt)
+        loss.backward()                  # DDP all-reduces (averages) the parameter gradients here
+        self.optimizer.step()
+        self.scheduler.step()
+        return loss.detach()
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    add_device_argument(ap)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="global batch (sharded over ranks)")
+    ap.add_argument("--size", type=int, default=64)
+    ap.add_argument("--features", type=int, default=64)
+    ap.add_argument("--backend", default=os.environ.get("ARTEMIS_DIST_BACKEND", "nccl"))
+    ap.add_argument("--composed", action="store_true", help="reference composition instead of the fused head")
+    ap.add_argument("--dump", default="", help="rank 0 writes the final parameters here (tests)")
+    args = ap.parse_args(argv)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and args.backend != "nccl" and args.device == "auto":
+        # rehearsal on fewer GPUs than ranks: wrap around the visible devices
+        args.device = str(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
+    device = select_device(args.device)
+    if world > 1:
+        kw = {"device_id": device} if args.backend == "nccl" else {}
+        torch.distributed.init_process_group(args.backend, **kw)
+    tr = HeadTrainer(device, num_features=args.features, fused=not args.composed)
+    for i in range(args.steps):
+        batch = synthetic_batch(args.batch, args.features, (args.size, args.size), 1000 + i, device)
+        loss = tr.step(batch)
+        if world > 1:
+            torch.distributed.all_reduce(loss, op=torch.distributed.ReduceOp.AVG
+                                         if args.backend == "nccl" else torch.distributed.ReduceOp.SUM)
+            if args.backend != "nccl":
+                loss /= world
+        if tr.rank == 0:
+            print(f"step {i}: loss {float(loss):.6f} lr {tr.scheduler.get_last_lr()[0]:.2e}", flush=True)
+    if args.dump and tr.rank == 0:
+        torch.save({k: v.detach().cpu() for k, v in tr.module.state_dict().items()}, args.dump)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
