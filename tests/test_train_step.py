@@ -14,6 +14,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def run_train(tmp_path, world, dump):
     env = dict(os.environ, PYTHONPATH=ROOT, ARTEMIS_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     args = ["--steps", "3", "--batch", "4", "--size", "48", "--features", "16", "--dump", dump]
@@ -21,7 +28,7 @@ def run_train(tmp_path, world, dump):
         cmd = [sys.executable, "-m", "artemis_amd.train", "--device", "hip:0"] + args
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
-               "--master-addr", "127.0.0.1", "--master-port", "29533", "-m", "artemis_amd.train",
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), "-m", "artemis_amd.train",
                "--backend", "gloo"] + args
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
