@@ -211,7 +211,7 @@ extern "C" {
 
 const char *artemis_synth_version(void)
 {
-    return "artemis_synth abi " "1" " gfx950 hip (fwd, fused bwd, grad_input atomic+deterministic)";
+    return "artemis_synth abi " "1" " gfx950 hip (fwd, fused bwd, grad_input atomic+deterministic, fused head, bf16 frames)";
 }
 
 const char *artemis_synth_last_error(void) { return g_last_error; }

@@ -23,8 +23,9 @@
  *    validation give hipErrorInvalidValue (1).  artemis_synth_last_error() returns a
  *    thread-local description of the last failure on the calling thread.  No exception crosses
  *    the boundary.
- *  - entry points are reentrant and hold no mutable global state: forward is called from the
- *    user's thread, backward from PyTorch's autograd thread.
+ *  - entry points are reentrant: forward is called from the user's thread, backward from PyTorch's
+ *    autograd thread.  The only mutable state of the library is one atomic tuning integer
+ *    (artemis_synth_set_small_grid_tiles); it never changes results.
  *  - empty problems (N, H or W equal to 0) are a successful no-op.
  *  - limits: one (H*W) plane and one padded frame plane must each hold fewer than 2^31
  *    elements; N <= 65535; total element counts are 64-bit (the reference's `const int n`
