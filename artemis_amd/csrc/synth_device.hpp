@@ -574,12 +574,57 @@ struct Float3 {
     float x, y, z;
 };
 
-// A tap is served from the staged tile iff both of its offsets satisfy |offset| < R + 1.  The
-// hot loops and the fix-ups below use this one predicate, so every tap is computed exactly once.
-template <int R>
-__device__ __forceinline__ bool tap_in_tile(float a, float b)
+// The staged tile is centred on the tile's typical displacement (cy, cx) -- whole pixels, wave-
+// uniform -- so that large coherent motion is served from LDS with a small radius.  A tap is
+// served from the tile iff its truncated offsets satisfy |trunc(a) - cy| <= R and
+// |trunc(b) - cx| <= R (for cy = cx = 0 that is |offset| < R + 1).  The hot loops and the fix-ups
+// below use this one predicate, so every tap is computed exactly once.  NaN truncates to 0.
+struct Centre {
+    float y, x;
+};
+
+__device__ __forceinline__ float tap_reach(float a, float b, Centre c)
 {
-    return fmaxf(fabsf(a), fabsf(b)) < (float)(R + 1);
+    const float da = (float)(int)a - c.y, db = (float)(int)b - c.x;
+    return fmaxf(fabsf(da), fabsf(db));
+}
+
+template <int R>
+__device__ __forceinline__ bool tap_in_tile(float a, float b, Centre c)
+{
+    return tap_reach(a, b, c) <= (float)R;
+}
+
+#ifndef SYNTH_CENTRE
+#define SYNTH_CENTRE 1
+#endif
+// Centre of one tile for one frame: the rounded mean offset of the 25 taps at the tile's middle
+// pixel (one 25-lane gather + a wave reduction per wave; every wave computes the same value).
+// Any value is correct; a representative one keeps the taps in the tile.  The tile is moved only
+// when that mean exceeds half the radius: for ordinary offsets the centre stays 0 and which taps
+// take the fix-up -- hence the last bit of a pixel -- does not depend on how the frame is tiled.
+template <int R>
+__device__ __forceinline__ Centre tile_centre(const float *__restrict__ ab,
+                                              const float *__restrict__ bb, size_t plane,
+                                              const Geom &g, int tx0, int ty0, int th)
+{
+    Centre c = {0.f, 0.f};
+#if SYNTH_CENTRE
+    const int l = threadIdx.x & 63;
+    const size_t pix = (size_t)min(ty0 + th / 2, g.H - 1) * g.W + min(tx0 + 32, g.W - 1);
+    float a = 0.f, b = 0.f;
+    if (l < 25) {
+        a = ab[(size_t)l * plane + pix];
+        b = bb[(size_t)l * plane + pix];
+    }
+    a = rintf(wave_sum(a) * (1.f / 25.f));
+    b = rintf(wave_sum(b) * (1.f / 25.f));
+    c.y = (fabsf(a) < 1.0e6f && fabsf(a) > 0.5f * R) ? a : 0.f;  // NaN / inf / absurd: no centring
+    c.x = (fabsf(b) < 1.0e6f && fabsf(b) > 0.5f * R) ? b : 0.f;
+    c.y = __builtin_amdgcn_readfirstlane(c.y);
+    c.x = __builtin_amdgcn_readfirstlane(c.x);
+#endif
+    return c;
 }
 
 // Contribution of ONE tap (clamped global gathers), channels 0..2.
@@ -605,7 +650,7 @@ template <int R, class FP>
 __device__ __forceinline__ Float3 fwd_outside_coop(FP ip,
                                                    const float *__restrict__ wb,
                                                    const float *__restrict__ ab,
-                                                   const float *__restrict__ bb, const Geom &g, int y,
+                                                   const float *__restrict__ bb, const Geom &g, Centre ctr, int y,
                                                    int xs)
 {
     const int l = threadIdx.x & 63;
@@ -614,7 +659,7 @@ __device__ __forceinline__ Float3 fwd_outside_coop(FP ip,
     if (l < 25) {
         const size_t o = (size_t)l * plane + (size_t)y * g.W + xs;
         const float a = ab[o], b = bb[o];
-        if (!tap_in_tile<R>(a, b)) {
+        if (!tap_in_tile<R>(a, b, ctr)) {
             const int r = l / 5, s = l - 5 * r;
             c = fwd_tap_global(ip, g, wb[o], a, b, y + g.oy0 + r, xs + g.ox0 + s);
         }
@@ -630,7 +675,7 @@ template <int R, class FP>
 __device__ __forceinline__ Float3 fwd_outside_lane(FP ip,
                                                    const float *__restrict__ wp,
                                                    const float *__restrict__ ap,
-                                                   const float *__restrict__ bp, const Geom &g, int y,
+                                                   const float *__restrict__ bp, const Geom &g, Centre ctr, int y,
                                                    int x)
 {
     const size_t plane = (size_t)g.H * g.W;
@@ -641,7 +686,7 @@ __device__ __forceinline__ Float3 fwd_outside_lane(FP ip,
         for (int s = 0; s < 5; ++s) {
             const size_t o = (size_t)(r * 5 + s) * plane;
             const float a = ap[o], b = bp[o];
-            if (!tap_in_tile<R>(a, b)) {
+            if (!tap_in_tile<R>(a, b, ctr)) {
                 const Float3 t = fwd_tap_global(ip, g, wp[o], a, b, y + g.oy0 + r, x + g.ox0 + s);
                 c.x += t.x;
                 c.y += t.y;
@@ -691,7 +736,7 @@ __device__ __forceinline__ float bwd_outside_coop(FP ip,
                                                   const float *__restrict__ bb,
                                                   const float *__restrict__ gn, float *__restrict__ gwn,
                                                   float *__restrict__ goyn, float *__restrict__ goxn,
-                                                  const Geom &g, int y, int xs, float scale,
+                                                  const Geom &g, Centre ctr, int y, int xs, float scale,
                                                   bool want_sum)
 {
     const int l = threadIdx.x & 63;
@@ -701,7 +746,7 @@ __device__ __forceinline__ float bwd_outside_coop(FP ip,
         const size_t pix = (size_t)y * g.W + xs;
         const size_t o = (size_t)l * plane + pix;
         const float a = ab[o], b = bb[o];
-        if (!tap_in_tile<R>(a, b)) {
+        if (!tap_in_tile<R>(a, b, ctr)) {
             const int r = l / 5, s = l - 5 * r;
             c = bwd_tap_global(ip, g, wb[o], a, b, gn[pix], gn[plane + pix], gn[2 * plane + pix],
                                y + g.oy0 + r, xs + g.ox0 + s, gwn, goyn, goxn, o, scale);
@@ -717,7 +762,7 @@ __device__ __forceinline__ float bwd_outside_lane(FP ip,
                                                   const float *__restrict__ bb, float d0, float d1,
                                                   float d2, float *__restrict__ gwn,
                                                   float *__restrict__ goyn, float *__restrict__ goxn,
-                                                  const Geom &g, int y, int x, float scale)
+                                                  const Geom &g, Centre ctr, int y, int x, float scale)
 {
     const size_t plane = (size_t)g.H * g.W;
     const size_t pix = (size_t)y * g.W + x;
@@ -728,7 +773,7 @@ __device__ __forceinline__ float bwd_outside_lane(FP ip,
         for (int s = 0; s < 5; ++s) {
             const size_t o = (size_t)(r * 5 + s) * plane + pix;
             const float a = ab[o], b = bb[o];
-            if (!tap_in_tile<R>(a, b))
+            if (!tap_in_tile<R>(a, b, ctr))
                 c += bwd_tap_global(ip, g, wb[o], a, b, d0, d1, d2, y + g.oy0 + r, x + g.ox0 + s, gwn,
                                     goyn, goxn, o, scale);
         }
@@ -936,13 +981,16 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
             }
         }
 
+        const Centre ctr = tile_centre<R>(ab, bb, pl, g, tx0, ty0, TH);
+        const int cyi = (int)ctr.y, cxi = (int)ctr.x;
         if (HEAD && f > 0) __syncthreads();  // every wave is done with the previous frame's tile
-        fill_tile_n<R, TH, 64 * WAVES>(tile, ip, g, ty0 + g.oy0 - R, tx0 + g.ox0 - R, tid);
+        fill_tile_n<R, TH, 64 * WAVES>(tile, ip, g, ty0 + g.oy0 - R + cyi, tx0 + g.ox0 - R + cxi, tid);
         __syncthreads();
         if (!active) {
             if constexpr (HEAD) continue;  // keeps taking part in the fills and barriers
             else return;
         }
+        const int cbase = (cyi * LW + cxi) * 16;  // the tile's shift, folded into the row bases
 
         float acc0[ROWS], acc1[ROWS], acc2[ROWS];
         float mabs[ROWS];
@@ -963,11 +1011,12 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
                 const float a = cur.a[j], b = cur.b[j];
                 const int ia = (int)a, ib = (int)b;
                 const float fa = a - (float)ia, fb = b - (float)ib;
-                mabs[j] = track_abs(mabs[j], a, b);
-                const Corners q = tile_corners_at<R, TH, r * LW + s>(ltile, ia, ib, rowbase[j]);
+                const float reach = fmaxf(fabsf((float)ia - ctr.y), fabsf((float)ib - ctr.x));
+                mabs[j] = fmaxf(mabs[j], reach);
+                const Corners q = tile_corners_at<R, TH, r * LW + s>(ltile, ia, ib, rowbase[j] - cbase);
                 const float ga = 1.f - fa, gb = 1.f - fb;
                 const float c00 = ga * gb, c10 = fa * gb, c01 = ga * fb, c11 = fa * fb;
-                wv = tap_in_tile<R>(a, b) ? wv : 0.f;  // a far tap is added by the fix-up instead
+                wv = reach <= (float)R ? wv : 0.f;  // a far tap is added by the fix-up instead
                 acc0[j] += wv * (q.bl.x * c00 + q.tl.x * c10 + q.br.x * c01 + q.tr.x * c11);
                 acc1[j] += wv * (q.bl.y * c00 + q.tl.y * c10 + q.br.y * c01 + q.tr.y * c11);
                 acc2[j] += wv * (q.bl.z * c00 + q.tl.z * c10 + q.br.z * c01 + q.tr.z * c11);
@@ -984,14 +1033,14 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) {
             // taps that left the tile are added through clamped global gathers
-            const bool flag = !(mabs[j] < (float)(R + 1));
+            const bool flag = !(mabs[j] <= (float)R);
             unsigned long long todo = __ballot(flag && tx0 + (int)threadIdx.x == x);
             if (todo) {  // wave-uniform, rare
                 if (__popcll(todo) <= kCoopMaxPixels) {
                     while (todo) {
                         const int b = __ffsll((long long)todo) - 1;
                         todo &= todo - 1;
-                        const Float3 c = fwd_outside_coop<R>(ip, wb, ab, bb, g, rowy[j], tx0 + b);
+                        const Float3 c = fwd_outside_coop<R>(ip, wb, ab, bb, g, ctr, rowy[j], tx0 + b);
                         if (x == tx0 + b) {  // the owner and its right-edge duplicates
                             acc0[j] += c.x;
                             acc1[j] += c.y;
@@ -1000,7 +1049,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
                     }
                 } else if (flag) {
                     const size_t o = rf[j] + x;
-                    const Float3 c = fwd_outside_lane<R>(ip, wb + o, ab + o, bb + o, g, rowy[j], x);
+                    const Float3 c = fwd_outside_lane<R>(ip, wb + o, ab + o, bb + o, g, ctr, rowy[j], x);
                     acc0[j] += c.x;
                     acc1[j] += c.y;
                     acc2[j] += c.z;
@@ -1093,13 +1142,16 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
             }
         }
 
+        const Centre ctr = tile_centre<R>(ab, bb, pl, g, tx0, ty0, TH);
+        const int cyi = (int)ctr.y, cxi = (int)ctr.x;
         if (HEAD && f > 0) __syncthreads();  // every wave is done with the previous frame's tile
-        fill_tile_n<R, TH, 64 * WAVES>(tile, ip, g, ty0 + g.oy0 - R, tx0 + g.ox0 - R, tid);
+        fill_tile_n<R, TH, 64 * WAVES>(tile, ip, g, ty0 + g.oy0 - R + cyi, tx0 + g.ox0 - R + cxi, tid);
         __syncthreads();
         if (!active) {
             if constexpr (HEAD) continue;
             else return;
         }
+        const int cbase = (cyi * LW + cxi) * 16;  // the tile's shift, folded into the row bases
 
         float mabs[ROWS];
         if (f == 0) {  // gradOutput is the same for every frame of the head
@@ -1123,8 +1175,9 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
                 const float wv = cur.w[j], a = cur.a[j], b = cur.b[j];
                 const int ia = (int)a, ib = (int)b;
                 const float fa = a - (float)ia, fb = b - (float)ib;
-                mabs[j] = track_abs(mabs[j], a, b);
-                const Corners q = tile_corners_at<R, TH, r * LW + s>(ltile, ia, ib, rowbase[j]);
+                const float reach = fmaxf(fabsf((float)ia - ctr.y), fabsf((float)ib - ctr.x));
+                mabs[j] = fmaxf(mabs[j], reach);
+                const Corners q = tile_corners_at<R, TH, r * LW + s>(ltile, ia, ib, rowbase[j] - cbase);
                 const float pbl = d[j][0] * q.bl.x + d[j][1] * q.bl.y + d[j][2] * q.bl.z;
                 const float ptl = d[j][0] * q.tl.x + d[j][1] * q.tl.y + d[j][2] * q.tl.z;
                 const float pbr = d[j][0] * q.br.x + d[j][1] * q.br.y + d[j][2] * q.br.z;
@@ -1138,7 +1191,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
                     const float gar = wv * (dl + fb * (dr - dl));
                     const float gbr = wv * across;
                     // a far tap's share comes from the fix-up, which also overwrites its stores
-                    gocc[j] += (tap_in_tile<R>(a, b) ? wv : 0.f) * gwr;
+                    gocc[j] += (reach <= (float)R ? wv : 0.f) * gwr;
                     if (ALL || gw) st_stream(gw + o + (unsigned)x, occv[j] * gwr);
                     if (ALL || goy) st_stream(goy + o + (unsigned)x, occv[j] * gar);
                     if (ALL || gox) st_stream(gox + o + (unsigned)x, occv[j] * gbr);
@@ -1158,7 +1211,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
         for (int j = 0; j < ROWS; ++j) {
             // taps that left the tile: recomputed through clamped global gathers, overwriting
             // what the hot loop stored for them (same lane or same wave: program order)
-            const bool flag = !(mabs[j] < (float)(R + 1));
+            const bool flag = !(mabs[j] <= (float)R);
             unsigned long long todo = __ballot(flag && tx0 + (int)threadIdx.x == x);
             if (todo) {  // wave-uniform, rare
                 float *gwn = gw ? gw + nb : nullptr, *goyn = goy ? goy + nb : nullptr,
@@ -1169,12 +1222,12 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
                         todo &= todo - 1;
                         const float sc = HEAD ? __shfl(occv[j], b) : 1.f;
                         const float c = bwd_outside_coop<R>(ip, wb, ab, bb, gb_, gwn, goyn, goxn, g,
-                                                            rowy[j], tx0 + b, sc, HEAD);
+                                                            ctr, rowy[j], tx0 + b, sc, HEAD);
                         if (HEAD && x == tx0 + b) gocc[j] += c;
                     }
                 } else if (flag) {
                     const float c = bwd_outside_lane<R>(ip, wb, ab, bb, d[j][0], d[j][1], d[j][2], gwn,
-                                                        goyn, goxn, g, rowy[j],
+                                                        goyn, goxn, g, ctr, rowy[j],
                                                         HEAD ? in_branch(x) : x,
                                                         HEAD ? occv[j] : 1.f);
                     if (HEAD) gocc[j] += c;

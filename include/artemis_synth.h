@@ -44,11 +44,13 @@ extern "C" {
 
 /* tile_radius: how far (in whole pixels) a tap may be displaced by its offsets and still be
  * served from the LDS-staged frame tile; larger displacements take a slower clamped global
- * gather, so every value is correct for any offset.  > 0 picks the smallest built tile radius
- * that covers it; ARTEMIS_SYNTH_RADIUS_DEFAULT lets the library choose; ARTEMIS_SYNTH_RADIUS_NONE
- * disables LDS staging (direct gathers through L1/L2).  Only k = 5, d = 1, C = 3 (the model's
- * configuration: config.py:26-27) has an LDS-staged kernel; other shapes always gather
- * directly. */
+ * gather, so every value is correct for any offset.  The displacement is measured from the tile's
+ * own centre: when the mean offset at the middle of a workgroup's tile exceeds half the radius, the
+ * staged window moves with it, so large coherent motion (a pan, a fast object) still runs from
+ * LDS.  > 0 picks the smallest built tile radius that covers it; ARTEMIS_SYNTH_RADIUS_DEFAULT
+ * lets the library choose; ARTEMIS_SYNTH_RADIUS_NONE disables LDS staging (direct gathers through
+ * L1/L2).  Only k = 5, d = 1, C = 3 (the model's configuration: config.py:26-27) has an
+ * LDS-staged kernel; other shapes always gather directly. */
 #define ARTEMIS_SYNTH_RADIUS_DEFAULT (-1)
 #define ARTEMIS_SYNTH_RADIUS_NONE 0
 

@@ -55,6 +55,18 @@ def main():
                     (up.flip(1) + torch.randn_like(up) * 0.1).contiguous())
         regimes.append(("smooth3", smooth))
 
+        def smooth30():  # large coherent motion: low-frequency field of +-30 px, 0.3 px noise
+            lo = torch.randn(N, 1, H // 128 + 2, W // 128 + 2, device=dev) * 15
+            up = torch.nn.functional.interpolate(lo, size=(H, W), mode="bicubic").expand(N, 25, H, W)
+            return ((up + torch.randn(N, 25, H, W, device=dev) * 0.3).contiguous(),
+                    (up.flip(3) + torch.randn(N, 25, H, W, device=dev) * 0.3).contiguous())
+        regimes.append(("smooth30", smooth30))
+
+        def pan():  # a camera pan: every tap displaced by (20, -35) px + N(0, 1)
+            return ((torch.randn(N, 25, H, W, device=dev) + 20.0).contiguous(),
+                    (torch.randn(N, 25, H, W, device=dev) - 35.0).contiguous())
+        regimes.append(("pan(20,-35)", pan))
+
     def timeit(fn):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
