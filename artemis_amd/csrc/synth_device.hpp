@@ -881,15 +881,6 @@ __device__ __forceinline__ Corners tile_corners_at(const lds_f32x4 *tile, int ia
     return q;
 }
 
-// |offset| < R + 1  =>  |trunc(offset)| <= R  =>  the footprint of every tap of every row of the
-// tile lies inside the staged tile.  One v_max3_f32 (with |.| source modifiers) per tap keeps the
-// running maximum; the comparison is made once per pixel.  NaN offsets truncate to 0 and stay in
-// the tile, so max's NaN-ignoring behaviour is the right one; +-inf is caught.
-__device__ __forceinline__ float track_abs(float m, float a, float b)
-{
-    return fmaxf(m, fmaxf(fabsf(a), fabsf(b)));
-}
-
 // The fused ChronoSynth head (HEAD = true; model/chrono_synth.py:114-129) runs the same body once
 // per context frame inside the workgroup: frame f's tile is staged, its 25 taps are applied with
 // the weights/offsets of slice [n, f] of the 5-D tensors read in place, and the result is folded
@@ -1302,6 +1293,10 @@ __global__ __launch_bounds__(64 * WAVES) void synth_gin_tiled(const float *__res
         roff[j] = (size_t)rowy[j] * g.W;
     }
 
+    // the accumulator window follows the motion like the forward's tile (tile_centre)
+    const Centre ctr = tile_centre<R>(ab, bb, plane, g, tx0, ty0, TH);
+    const int cyi = (int)ctr.y, cxi = (int)ctr.x;
+
     TapCol<ROWS> cur;
     load_tap_col<ROWS>(cur, wb, ab, bb, plane, 0, roff, (unsigned)x);
     for (int i = tid; i < 3 * CS; i += 64 * WAVES) acc[i] = 0;
@@ -1317,7 +1312,7 @@ __global__ __launch_bounds__(64 * WAVES) void synth_gin_tiled(const float *__res
         d[j][1] = ld_stream(gb_ + plane + roff[j] + (unsigned)x) * on;
         d[j][2] = ld_stream(gb_ + 2 * plane + roff[j] + (unsigned)x) * on;
         mabs[j] = 0.f;
-        rowbase[j] = (rowy[j] - ty0 + R) * LW + px + R;
+        rowbase[j] = (rowy[j] - ty0 + R - cyi) * LW + px + R - cxi;
     }
     static_for<0, 25>([&](auto tc) {
         constexpr int t = decltype(tc)::value;
@@ -1330,8 +1325,9 @@ __global__ __launch_bounds__(64 * WAVES) void synth_gin_tiled(const float *__res
             const float wv = cur.w[j], a = cur.a[j], b = cur.b[j];
             const int ia = (int)a, ib = (int)b;
             const float fa = a - (float)ia, fb = b - (float)ib;
-            mabs[j] = track_abs(mabs[j], a, b);
-            if (fmaxf(fabsf(a), fabsf(b)) < (float)(R + 1)) {  // footprint inside the tile
+            const float reach = fmaxf(fabsf((float)ia - ctr.y), fabsf((float)ib - ctr.x));
+            mabs[j] = fmaxf(mabs[j], reach);
+            if (reach <= (float)R) {  // footprint inside the window
                 acc_t *p = acc + (__mul24(ia, LW) + ib + rowbase[j] + (r * LW + s));
                 const float ga = 1.f - fa, gb = 1.f - fb;
                 const float c00 = ga * gb, c10 = fa * gb, c01 = ga * fb, c11 = fa * fb;
@@ -1352,7 +1348,7 @@ __global__ __launch_bounds__(64 * WAVES) void synth_gin_tiled(const float *__res
     __syncthreads();
 
     // flush the tile: texel (ly, lx) is frame pixel (clamp(gy0 + ly), clamp(gx0 + lx))
-    const int gy0 = ty0 + g.oy0 - R, gx0 = tx0 + g.ox0 - R;
+    const int gy0 = ty0 + g.oy0 - R + cyi, gx0 = tx0 + g.ox0 - R + cxi;
     for (int i = tid; i < CS; i += 64 * WAVES) {
         const int ly = i / LW, lx = i - ly * LW;
         const int gy = clampi(gy0 + ly, 0, g.Hin - 1), gx = clampi(gx0 + lx, 0, g.Win - 1);
@@ -1372,14 +1368,14 @@ __global__ __launch_bounds__(64 * WAVES) void synth_gin_tiled(const float *__res
     // taps that left the tile: straight to memory, lane by lane (rare)
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) {
-        if (!(mabs[j] < (float)(R + 1)) && lane_on && rowon[j]) {
+        if (!(mabs[j] <= (float)R) && lane_on && rowon[j]) {
             const int y = rowy[j];
             const size_t pix = roff[j] + x;
 #pragma unroll 1
             for (int t = 0; t < 25; ++t) {
                 const size_t o = (size_t)t * plane + pix;
                 const float a = ab[o], b = bb[o];
-                if (fmaxf(fabsf(a), fabsf(b)) < (float)(R + 1)) continue;
+                if (tap_in_tile<R>(a, b, ctr)) continue;
                 const float wv = wb[o];
                 const int r = t / 5, s2 = t - 5 * r;
                 const TapIdx ti = tap_index(g, a, b, y + g.oy0 + r, x + g.ox0 + s2);
