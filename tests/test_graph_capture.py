@@ -1,7 +1,6 @@
 """The library only enqueues kernels and memsets on the stream it is given, so its calls can be
 captured into a HIP graph (torch.cuda.CUDAGraph) and replayed: the small heads of a training step
 are launch-bound, and a replayed graph removes the per-launch host cost."""
-import numpy as np
 import pytest
 import torch
 
@@ -11,9 +10,9 @@ pytestmark = pytest.mark.gpu
 
 
 def test_head_forward_backward_replays_from_a_hip_graph():
-    import artemis_amd
-    from artemis_amd import _lib
     import ctypes
+
+    from artemis_amd import _lib
     dev = torch.device("cuda:0")
     lib = _lib.load()
     B, T, H, W = 2, 4, 48, 80

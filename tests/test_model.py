@@ -4,7 +4,6 @@ selection.  CPU: state-dict compatibility with the upstream module's parameter n
 fused forward/backward against the same module running the reference's per-frame composition."""
 import argparse
 
-import numpy as np
 import pytest
 import torch
 

@@ -1,11 +1,10 @@
 #!/usr/bin/env python3
 """A/B of gradInput (atomic mode) across builds in one process.  usage: gin_ab.py lib... [--radius R]"""
-import ctypes, os, statistics, sys
+import os, statistics, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
-from artemis_amd import _lib
 from tools.ab import bind
 
 radius = -1
