@@ -94,13 +94,14 @@ inline dim3 pixel_grid(const Geom &g, int rows_per_block)
 #ifndef SYNTH_XCD_REMAP
 #define SYNTH_XCD_REMAP 1
 #endif
-inline dim3 tile_grid(const Geom &g, int rows_per_block)
+inline dim3 tile_grid(const Geom &g, int rows_per_block, int cols_per_block = 64)
 {
+    const unsigned tiles_x = (unsigned)((g.W + cols_per_block - 1) / cols_per_block);
+    const unsigned tiles_y = (unsigned)((g.H + rows_per_block - 1) / rows_per_block);
 #if SYNTH_XCD_REMAP
-    const unsigned nb = (unsigned)((g.W + 63) / 64) * (unsigned)((g.H + rows_per_block - 1) / rows_per_block);
-    return dim3(((nb + 7) / 8) * 8, 1, (unsigned)g.N);
+    return dim3(((tiles_x * tiles_y + 7) / 8) * 8, 1, (unsigned)g.N);
 #else
-    return pixel_grid(g, rows_per_block);
+    return dim3(tiles_x, tiles_y, (unsigned)g.N);
 #endif
 }
 
@@ -128,20 +129,20 @@ __device__ __forceinline__ const float *frame_view(const float *p) { return p; }
 __device__ __forceinline__ Bf16View frame_view(const bf16_t *p) { return Bf16View{p}; }
 
 // tile origin of this workgroup; false: no tile (only with SYNTH_XCD_REMAP)
-template <int TH>
+template <int TH, int TW>
 __device__ __forceinline__ bool tile_origin(const Geom &g, int &tx0, int &ty0)
 {
 #if SYNTH_XCD_REMAP
-    const unsigned tiles_x = (unsigned)(g.W + 63) / 64, tiles_y = (unsigned)(g.H + TH - 1) / TH;
+    const unsigned tiles_x = (unsigned)(g.W + TW - 1) / TW, tiles_y = (unsigned)(g.H + TH - 1) / TH;
     const unsigned nb = tiles_x * tiles_y, per = (nb + 7) / 8;
     const unsigned t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if (t >= nb) return false;
     const unsigned ty = t / tiles_x;
-    tx0 = (int)(t - ty * tiles_x) * 64;
+    tx0 = (int)(t - ty * tiles_x) * TW;
     ty0 = (int)ty * TH;
     return true;
 #else
-    tx0 = blockIdx.x * 64;
+    tx0 = blockIdx.x * TW;
     ty0 = blockIdx.y * TH;
     return true;
 #endif
@@ -520,9 +521,9 @@ __device__ __forceinline__ void static_for(F &&f)
     }
 }
 
-template <int R, int TH>
+template <int R, int TH, int TW = kTW>
 struct TileShape {
-    static constexpr int LW = kTW + 5 + 2 * R;
+    static constexpr int LW = TW + 5 + 2 * R;
     static constexpr int LH = TH + 5 + 2 * R;
 };
 
@@ -606,12 +607,12 @@ __device__ __forceinline__ bool tap_in_tile(float a, float b, Centre c)
 template <int R>
 __device__ __forceinline__ Centre tile_centre(const float *__restrict__ ab,
                                               const float *__restrict__ bb, size_t plane,
-                                              const Geom &g, int tx0, int ty0, int th)
+                                              const Geom &g, int tx0, int ty0, int th, int tw = 64)
 {
     Centre c = {0.f, 0.f};
 #if SYNTH_CENTRE
     const int l = threadIdx.x & 63;
-    const size_t pix = (size_t)min(ty0 + th / 2, g.H - 1) * g.W + min(tx0 + 32, g.W - 1);
+    const size_t pix = (size_t)min(ty0 + th / 2, g.H - 1) * g.W + min(tx0 + tw / 2, g.W - 1);
     float a = 0.f, b = 0.f;
     if (l < 25) {
         a = ab[(size_t)l * plane + pix];
@@ -822,13 +823,16 @@ __device__ __forceinline__ void load_tap_col(TapCol<ROWS> &t, const float *__res
 // Stage the clamped frame tile.  Texels are fetched in batches of kFillBatch per lane with all of
 // a batch's loads issued before the first LDS write: left to itself hipcc waits vmcnt(0) after
 // every texel, which serialises ~14 L2 round trips (~10 us) at the head of every workgroup.
-constexpr int kFillBatch = 7;
+#ifndef SYNTH_FILL_BATCH
+#define SYNTH_FILL_BATCH 11
+#endif
+constexpr int kFillBatch = SYNTH_FILL_BATCH;
 
-template <int R, int TH, int THREADS, class FP>
+template <int R, int TH, int THREADS, int TW, class FP>
 __device__ __forceinline__ void fill_tile_n(f32x4 *tile, FP ip, const Geom &g,
                                             int gy0, int gx0, int tid)
 {
-    constexpr int LW = TileShape<R, TH>::LW, LH = TileShape<R, TH>::LH;
+    constexpr int LW = TileShape<R, TH, TW>::LW, LH = TileShape<R, TH, TW>::LH;
     constexpr int N = LH * LW;
     const int iplane = g.Hin * g.Win;
 #pragma unroll 1
@@ -864,11 +868,11 @@ struct Corners {
 // immediate offset, so a tap costs v_mad_i32_i24 + v_lshl_add_u32 + v_min_u32.
 // The unsigned min keeps the four reads in bounds whatever the offsets are (a negative address
 // is a huge unsigned); a tap that really is outside is caught by the |offset| test below.
-template <int R, int TH, int TAPOFF>
+template <int R, int TH, int TAPOFF, int TW>
 __device__ __forceinline__ Corners tile_corners_at(const lds_f32x4 *tile, int ia, int ib,
                                                    int rowbase)
 {
-    constexpr int LW = TileShape<R, TH>::LW, LH = TileShape<R, TH>::LH;
+    constexpr int LW = TileShape<R, TH, TW>::LW, LH = TileShape<R, TH, TW>::LH;
     const unsigned addr = (unsigned)(__mul24(ia, LW * 16) + rowbase + (ib << 4));
     const unsigned safe = min(addr, (unsigned)(((LH - 1) * LW - 2 - TAPOFF) * 16));
     const lds_f32x4 *p =
@@ -908,26 +912,28 @@ __device__ __forceinline__ int in_branch(int v)
 }
 
 
-template <int R, int WAVES, int ROWS, int OCC, bool HEAD, class FT>
+template <int R, int WAVES, int ROWS, int OCC, bool HEAD, class FT, int WX = 1>
 __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
     const FT *__restrict__ in, const float *__restrict__ w, const float *__restrict__ oy,
     const float *__restrict__ ox, float *__restrict__ out, Geom g, HeadArgs ha)
 {
-    constexpr int TH = WAVES * ROWS;
-    constexpr int LW = TileShape<R, TH>::LW, LH = TileShape<R, TH>::LH;
+    // WX waves side by side: the tile is 64 * WX pixels wide and (WAVES / WX) * ROWS rows high
+    constexpr int TW = 64 * WX, WY = WAVES / WX, TH = WY * ROWS;
+    constexpr int LW = TileShape<R, TH, TW>::LW, LH = TileShape<R, TH, TW>::LH;
     __shared__ f32x4 tile[LH * LW];
     const lds_f32x4 *ltile = (const lds_f32x4 *)tile;
     int tx0, ty0;
-    if (!tile_origin<TH>(g, tx0, ty0)) return;
+    if (!tile_origin<TH, TW>(g, tx0, ty0)) return;
     const int n = blockIdx.z;
-    const int wy = __builtin_amdgcn_readfirstlane(threadIdx.y);
-    const int tid = wy * 64 + threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int wy = wv / WX, wx0 = tx0 + (wv % WX) * 64;  // the wave's first row slot and column
+    const int tid = wv * 64 + threadIdx.x;
     const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
     // A lane past the right edge acts as the last image column (same operands, same arithmetic,
     // same stores as that column's owner), like the rows below: no lane ever retires on its own,
     // so wave-wide operations in the fix-up see all 64 lanes.
-    const int x = min(tx0 + (int)threadIdx.x, g.W - 1), px = x - tx0;
-    const bool active = ty0 + wy < g.H;  // wave-uniform
+    const int x = min(wx0 + (int)threadIdx.x, g.W - 1), px = x - tx0;
+    const bool active = ty0 + wy < g.H && wx0 < g.W;  // wave-uniform
 
     // A row past the bottom edge is replaced by the last image row: the wave then recomputes
     // and re-stores exactly what that row's owner stores (same operands, same arithmetic), which
@@ -937,7 +943,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
     int rowbase[ROWS];
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) {
-        rowy[j] = min(ty0 + wy + WAVES * j, g.H - 1);
+        rowy[j] = min(ty0 + wy + WY * j, g.H - 1);
         roff[j] = (size_t)rowy[j] * g.W;
         rowbase[j] = ((rowy[j] - ty0 + R) * LW + px + R) * 16;
     }
@@ -972,10 +978,10 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
             }
         }
 
-        const Centre ctr = tile_centre<R>(ab, bb, pl, g, tx0, ty0, TH);
+        const Centre ctr = tile_centre<R>(ab, bb, pl, g, tx0, ty0, TH, TW);
         const int cyi = (int)ctr.y, cxi = (int)ctr.x;
         if (HEAD && f > 0) __syncthreads();  // every wave is done with the previous frame's tile
-        fill_tile_n<R, TH, 64 * WAVES>(tile, ip, g, ty0 + g.oy0 - R + cyi, tx0 + g.ox0 - R + cxi, tid);
+        fill_tile_n<R, TH, 64 * WAVES, TW>(tile, ip, g, ty0 + g.oy0 - R + cyi, tx0 + g.ox0 - R + cxi, tid);
         __syncthreads();
         if (!active) {
             if constexpr (HEAD) continue;  // keeps taking part in the fills and barriers
@@ -1004,7 +1010,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
                 const float fa = a - (float)ia, fb = b - (float)ib;
                 const float reach = fmaxf(fabsf((float)ia - ctr.y), fabsf((float)ib - ctr.x));
                 mabs[j] = fmaxf(mabs[j], reach);
-                const Corners q = tile_corners_at<R, TH, r * LW + s>(ltile, ia, ib, rowbase[j] - cbase);
+                const Corners q = tile_corners_at<R, TH, r * LW + s, TW>(ltile, ia, ib, rowbase[j] - cbase);
                 const float ga = 1.f - fa, gb = 1.f - fb;
                 const float c00 = ga * gb, c10 = fa * gb, c01 = ga * fb, c11 = fa * fb;
                 wv = reach <= (float)R ? wv : 0.f;  // a far tap is added by the fix-up instead
@@ -1025,14 +1031,14 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
         for (int j = 0; j < ROWS; ++j) {
             // taps that left the tile are added through clamped global gathers
             const bool flag = !(mabs[j] <= (float)R);
-            unsigned long long todo = __ballot(flag && tx0 + (int)threadIdx.x == x);
+            unsigned long long todo = __ballot(flag && wx0 + (int)threadIdx.x == x);
             if (todo) {  // wave-uniform, rare
                 if (__popcll(todo) <= kCoopMaxPixels) {
                     while (todo) {
                         const int b = __ffsll((long long)todo) - 1;
                         todo &= todo - 1;
-                        const Float3 c = fwd_outside_coop<R>(ip, wb, ab, bb, g, ctr, rowy[j], tx0 + b);
-                        if (x == tx0 + b) {  // the owner and its right-edge duplicates
+                        const Float3 c = fwd_outside_coop<R>(ip, wb, ab, bb, g, ctr, rowy[j], wx0 + b);
+                        if (x == wx0 + b) {  // the owner and its right-edge duplicates
                             acc0[j] += c.x;
                             acc1[j] += c.y;
                             acc2[j] += c.z;
@@ -1073,32 +1079,34 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
 // out = sum_f occ_f * S_f; per frame the kernel forms the unscaled tap gradients from it, stores
 // them times occ_f into slice [n, f] of the 5-D gradient tensors in place, and accumulates
 // gocc[n, f] = sum_c gradOutput_c * S_f,c = sum_t w_t * (unscaled gradWeight_t) in registers.
-template <int R, int WAVES, int ROWS, int OCC, bool ALL, bool HEAD, class FT>
+template <int R, int WAVES, int ROWS, int OCC, bool ALL, bool HEAD, class FT, int WX = 1>
 __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
     const FT *__restrict__ in, const float *__restrict__ w, const float *__restrict__ oy,
     const float *__restrict__ ox, const float *__restrict__ gout, float *__restrict__ gw,
     float *__restrict__ goy, float *__restrict__ gox, Geom g, HeadArgs ha)
 {
-    constexpr int TH = WAVES * ROWS;
-    constexpr int LW = TileShape<R, TH>::LW, LH = TileShape<R, TH>::LH;
+    // WX waves side by side: the tile is 64 * WX pixels wide and (WAVES / WX) * ROWS rows high
+    constexpr int TW = 64 * WX, WY = WAVES / WX, TH = WY * ROWS;
+    constexpr int LW = TileShape<R, TH, TW>::LW, LH = TileShape<R, TH, TW>::LH;
     __shared__ f32x4 tile[LH * LW];
     const lds_f32x4 *ltile = (const lds_f32x4 *)tile;
     int tx0, ty0;
-    if (!tile_origin<TH>(g, tx0, ty0)) return;
+    if (!tile_origin<TH, TW>(g, tx0, ty0)) return;
     const int n = blockIdx.z;
-    const int wy = __builtin_amdgcn_readfirstlane(threadIdx.y);
-    const int tid = wy * 64 + threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int wy = wv / WX, wx0 = tx0 + (wv % WX) * 64;  // the wave's first row slot and column
+    const int tid = wv * 64 + threadIdx.x;
     const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
     // lanes past the right edge duplicate the last image column (see forward)
-    const int x = min(tx0 + (int)threadIdx.x, g.W - 1), px = x - tx0;
-    const bool active = ty0 + wy < g.H;  // wave-uniform
+    const int x = min(wx0 + (int)threadIdx.x, g.W - 1), px = x - tx0;
+    const bool active = ty0 + wy < g.H && wx0 < g.W;  // wave-uniform
 
     int rowy[ROWS];  // rows past the bottom edge duplicate the last image row (see forward)
     size_t roff[ROWS];
     int rowbase[ROWS];
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) {
-        rowy[j] = min(ty0 + wy + WAVES * j, g.H - 1);
+        rowy[j] = min(ty0 + wy + WY * j, g.H - 1);
         roff[j] = (size_t)rowy[j] * g.W;
         rowbase[j] = ((rowy[j] - ty0 + R) * LW + px + R) * 16;
     }
@@ -1133,10 +1141,10 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
             }
         }
 
-        const Centre ctr = tile_centre<R>(ab, bb, pl, g, tx0, ty0, TH);
+        const Centre ctr = tile_centre<R>(ab, bb, pl, g, tx0, ty0, TH, TW);
         const int cyi = (int)ctr.y, cxi = (int)ctr.x;
         if (HEAD && f > 0) __syncthreads();  // every wave is done with the previous frame's tile
-        fill_tile_n<R, TH, 64 * WAVES>(tile, ip, g, ty0 + g.oy0 - R + cyi, tx0 + g.ox0 - R + cxi, tid);
+        fill_tile_n<R, TH, 64 * WAVES, TW>(tile, ip, g, ty0 + g.oy0 - R + cyi, tx0 + g.ox0 - R + cxi, tid);
         __syncthreads();
         if (!active) {
             if constexpr (HEAD) continue;
@@ -1168,7 +1176,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
                 const float fa = a - (float)ia, fb = b - (float)ib;
                 const float reach = fmaxf(fabsf((float)ia - ctr.y), fabsf((float)ib - ctr.x));
                 mabs[j] = fmaxf(mabs[j], reach);
-                const Corners q = tile_corners_at<R, TH, r * LW + s>(ltile, ia, ib, rowbase[j] - cbase);
+                const Corners q = tile_corners_at<R, TH, r * LW + s, TW>(ltile, ia, ib, rowbase[j] - cbase);
                 const float pbl = d[j][0] * q.bl.x + d[j][1] * q.bl.y + d[j][2] * q.bl.z;
                 const float ptl = d[j][0] * q.tl.x + d[j][1] * q.tl.y + d[j][2] * q.tl.z;
                 const float pbr = d[j][0] * q.br.x + d[j][1] * q.br.y + d[j][2] * q.br.z;
@@ -1203,7 +1211,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
             // taps that left the tile: recomputed through clamped global gathers, overwriting
             // what the hot loop stored for them (same lane or same wave: program order)
             const bool flag = !(mabs[j] <= (float)R);
-            unsigned long long todo = __ballot(flag && tx0 + (int)threadIdx.x == x);
+            unsigned long long todo = __ballot(flag && wx0 + (int)threadIdx.x == x);
             if (todo) {  // wave-uniform, rare
                 float *gwn = gw ? gw + nb : nullptr, *goyn = goy ? goy + nb : nullptr,
                       *goxn = gox ? gox + nb : nullptr;
@@ -1213,8 +1221,8 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
                         todo &= todo - 1;
                         const float sc = HEAD ? __shfl(occv[j], b) : 1.f;
                         const float c = bwd_outside_coop<R>(ip, wb, ab, bb, gb_, gwn, goyn, goxn, g,
-                                                            ctr, rowy[j], tx0 + b, sc, HEAD);
-                        if (HEAD && x == tx0 + b) gocc[j] += c;
+                                                            ctr, rowy[j], wx0 + b, sc, HEAD);
+                        if (HEAD && x == wx0 + b) gocc[j] += c;
                     }
                 } else if (flag) {
                     const float c = bwd_outside_lane<R>(ip, wb, ab, bb, d[j][0], d[j][1], d[j][2], gwn,

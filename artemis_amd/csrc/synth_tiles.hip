@@ -14,27 +14,32 @@
 
 namespace {
 
-// Tile configuration per built radius (tools/ab.py compares builds in one process; the
-// SYNTH_* macros override the R <= 8 shape for such experiments).
-//   R <= 8 : 4 waves x 8 rows  = 64 x 32 pixels, LDS 47.9 / 55.4 / 72.1 KB, 2 workgroups per CU
-//   R = 16 : 8 waves x 4 rows  = 64 x 32 pixels, LDS 111.5 KB, 1 workgroup (8 waves) per CU
+// Tile configuration (tools/ab.py compares builds in one process; the SYNTH_* macros override the
+// shape for such experiments).  Every radius: 8 waves as 2 across x 4 down, 4 rows per wave =
+// 128 x 16 pixels, ONE workgroup per CU (LDS 53 / 64 / 88 / 140 KB for R = 2 / 4 / 8 / 16; the small
+// radii are padded with dynamic LDS so that a second workgroup does not fit).  Measured with
+// stream-only stand-ins (tools/exp/exp_stream.hip, backward-like, 1080p): 64 x 32 tiles, two
+// workgroups per CU 240 us; one per CU 231 us; 128 x 16, one per CU 224 us; 128 x 16, two per CU 241 us.
 #ifndef SYNTH_WAVES
-#define SYNTH_WAVES 4
+#define SYNTH_WAVES 8
+#endif
+#ifndef SYNTH_WX
+#define SYNTH_WX 2
 #endif
 #ifndef SYNTH_ROWS
-#define SYNTH_ROWS 8
+#define SYNTH_ROWS 4
 #endif
 #ifndef SYNTH_OCC
 #define SYNTH_OCC 2
 #endif
+#ifndef SYNTH_ONE_WG_PER_CU
+#define SYNTH_ONE_WG_PER_CU 1
+#endif
 
 template <int R>
 struct TileCfg {
-    static constexpr int WAVES = SYNTH_WAVES, ROWS = SYNTH_ROWS, OCC = SYNTH_OCC;
-};
-template <>
-struct TileCfg<16> {
-    static constexpr int WAVES = 8, ROWS = 4, OCC = 2;
+    static constexpr int WAVES = SYNTH_WAVES, WX = SYNTH_WX, ROWS = SYNTH_ROWS, OCC = SYNTH_OCC;
+    static constexpr bool kSolo = SYNTH_ONE_WG_PER_CU;
 };
 
 // Small grids: a problem with fewer than small_grid_tiles() (default 768) tiles of 64 x 32 pixels (the 64^2 and 128^2
@@ -43,8 +48,18 @@ struct TileCfg<16> {
 // 4x the workgroups, each a quarter of the work.  Same per-pixel arithmetic, same bits.
 
 struct SmallCfg {
-    static constexpr int WAVES = 4, ROWS = 2, OCC = 2;
+    static constexpr int WAVES = 4, WX = 1, ROWS = 2, OCC = 2;
+    static constexpr bool kSolo = false;
 };
+
+// dynamic LDS that keeps a second workgroup off the CU (160 KB per CU) when the config wants that
+template <int R, class T>
+unsigned lds_pad()
+{
+    constexpr int TH = (T::WAVES / T::WX) * T::ROWS, TW = 64 * T::WX;
+    constexpr int bytes = TileShape<R, TH, TW>::LW * TileShape<R, TH, TW>::LH * 16;
+    return (T::kSolo && bytes < 82 * 1024) ? (unsigned)(82 * 1024 - bytes) : 0u;
+}
 
 // The backward (more work per tile, more sensitive to a ragged last round of workgroups) switches
 // at the knob, the forward at a quarter of it: measured crossovers on 256 CUs are ~770 and ~160
@@ -52,7 +67,8 @@ struct SmallCfg {
 template <class T>
 bool small_grid(const asynth::Geom &g, bool backward)
 {
-    const long long tiles = (long long)((g.W + 63) / 64) * ((g.H + T::WAVES * T::ROWS - 1) / (T::WAVES * T::ROWS)) * g.N;
+    // counted in 64 x 32 units whatever the big tile's shape is
+    const long long tiles = (long long)((g.W + 63) / 64) * ((g.H + 31) / 32) * g.N;
     const long long knob = asynth::small_grid_tiles();
     return tiles < (backward ? knob : (knob + 3) / 4);
 }
@@ -61,13 +77,14 @@ template <int R, class T, class FT>
 void fwd_cfg(bool head, const FT *in, const float *w, const float *oy, const float *ox, float *out,
              const asynth::Geom &g, const asynth::HeadArgs &ha, hipStream_t st)
 {
-    const dim3 grid = asynth::tile_grid(g, T::WAVES * T::ROWS), block(64, T::WAVES);
+    const dim3 grid = asynth::tile_grid(g, (T::WAVES / T::WX) * T::ROWS, 64 * T::WX), block(64, T::WAVES);
+    const unsigned pad = lds_pad<R, T>();
     if (head)
-        hipLaunchKernelGGL((synth_fwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true, FT>), grid, block, 0, st,
-                           in, w, oy, ox, out, g, ha);
+        hipLaunchKernelGGL((synth_fwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true, FT, T::WX>), grid, block,
+                           pad, st, in, w, oy, ox, out, g, ha);
     else
-        hipLaunchKernelGGL((synth_fwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false, FT>), grid, block, 0,
-                           st, in, w, oy, ox, out, g, ha);
+        hipLaunchKernelGGL((synth_fwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false, FT, T::WX>), grid, block,
+                           pad, st, in, w, oy, ox, out, g, ha);
 }
 
 template <int R, class T, class FT>
@@ -75,22 +92,23 @@ void bwd_cfg(bool head, const FT *in, const float *w, const float *oy, const flo
              const float *gout, float *gw, float *goy, float *gox, const asynth::Geom &g,
              const asynth::HeadArgs &ha, hipStream_t st)
 {
-    const dim3 grid = asynth::tile_grid(g, T::WAVES * T::ROWS), block(64, T::WAVES);
+    const dim3 grid = asynth::tile_grid(g, (T::WAVES / T::WX) * T::ROWS, 64 * T::WX), block(64, T::WAVES);
+    const unsigned pad = lds_pad<R, T>();
     const bool all = gw && goy && gox;
     if (head) {
         if (all)
-            hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true, true, FT>), grid,
-                               block, 0, st, in, w, oy, ox, gout, gw, goy, gox, g, ha);
+            hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true, true, FT, T::WX>), grid,
+                               block, pad, st, in, w, oy, ox, gout, gw, goy, gox, g, ha);
         else
-            hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false, true, FT>), grid,
-                               block, 0, st, in, w, oy, ox, gout, gw, goy, gox, g, ha);
+            hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false, true, FT, T::WX>), grid,
+                               block, pad, st, in, w, oy, ox, gout, gw, goy, gox, g, ha);
     } else {
         if (all)
-            hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true, false, FT>), grid,
-                               block, 0, st, in, w, oy, ox, gout, gw, goy, gox, g, ha);
+            hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true, false, FT, T::WX>), grid,
+                               block, pad, st, in, w, oy, ox, gout, gw, goy, gox, g, ha);
         else
-            hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false, false, FT>), grid,
-                               block, 0, st, in, w, oy, ox, gout, gw, goy, gox, g, ha);
+            hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false, false, FT, T::WX>), grid,
+                               block, pad, st, in, w, oy, ox, gout, gw, goy, gox, g, ha);
     }
 }
 

@@ -107,9 +107,10 @@ def test_head_both_tile_shapes(dev, oracle, knob, radius):
     out_b, g_b = run()
     knob(ALWAYS_SMALL)
     out_s, g_s = run()
-    assert torch.equal(out_b, out_s)
+    exact = not may_recentre("gauss4", radius)
+    same(out_b, out_s, exact, "framet")
     for x, y in zip(g_b, g_s):
-        assert torch.equal(x, y)
+        same(x, y, exact, "gradients")
     ref, _ = oracle.head_forward(frames, w, a, b, occ, 1)
     close(out_b, ref, FWD_RTOL, "framet")
     for g, r in zip(g_b, oracle.head_backward(gout, frames, w, a, b, occ, 1)):

@@ -571,6 +571,86 @@ static void ltmh(const float *w, const float *oy, const float *ox, float *gw, fl
     hipLaunchKernelGGL((stream_tapmajor_h<LDSB, VEC, RW, BWD, NT>), grid, dim3(64, 4), 0, st, w, oy, ox, gw, ga, gb, H, W);
 }
 
+// 128-pixel-wide workgroup tiles with one pixel per lane: 8 waves as 2 (x) x 4 (y), dword accesses.
+// Separates "wider tile per workgroup" from "wider access per lane" (stream_tapmajor_v).
+template <int LDSB, int RW, bool BWD>
+__global__ __launch_bounds__(512) void stream_tapmajor_w(const float *__restrict__ w, const float *__restrict__ oy,
+                                                  const float *__restrict__ ox, float *__restrict__ gw,
+                                                  float *__restrict__ ga, float *__restrict__ gb,
+                                                  int H, int W)
+{
+    __shared__ float dummy[LDSB / 4];
+    if (LDSB > 4 && threadIdx.x == 999) dummy[threadIdx.y] = 0;
+    constexpr int TH = 4 * RW;
+    const unsigned tiles_x = (unsigned)(W + 127) / 128, tiles_y = (unsigned)(H + TH - 1) / TH;
+    const unsigned nb = tiles_x * tiles_y, per = (nb + 7) / 8;
+    const unsigned t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (t >= nb) return;
+    const unsigned ty = t / tiles_x;
+    const int tx0 = (int)(t - ty * tiles_x) * 128, ty0 = (int)ty * TH;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int wx = wv & 1, wy = wv >> 1;
+    const unsigned x = tx0 + wx * 64 + threadIdx.x;
+    if ((int)x >= W) return;
+    const size_t plane = (size_t)H * W;
+    float buf[2][3 * RW];
+    float acc[3 * RW];
+#pragma unroll
+    for (int i = 0; i < 3 * RW; ++i) acc[i] = 0;
+    auto issue = [&](int tt, float *dst) {
+#pragma unroll
+        for (int j = 0; j < RW; ++j) {
+            const int y = min(ty0 + wy + 4 * j, H - 1);
+            const size_t o = (size_t)y * W + (size_t)tt * plane;
+            dst[3 * j] = __builtin_nontemporal_load(w + o + x);
+            dst[3 * j + 1] = __builtin_nontemporal_load(oy + o + x);
+            dst[3 * j + 2] = __builtin_nontemporal_load(ox + o + x);
+        }
+    };
+    issue(0, buf[0]);
+#pragma unroll
+    for (int tt = 0; tt < 25; ++tt) {
+        if (tt + 1 < 25) issue(tt + 1, buf[(tt + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        float *c = buf[tt & 1];
+#pragma unroll
+        for (int j = 0; j < RW; ++j) {
+            const int y = ty0 + wy + 4 * j;
+            if (BWD) {
+                if (y < H) {
+                    const size_t o = (size_t)y * W + (size_t)tt * plane;
+                    __builtin_nontemporal_store(c[3 * j] * 1.5f, gw + o + x);
+                    __builtin_nontemporal_store(c[3 * j + 1] + c[3 * j], ga + o + x);
+                    __builtin_nontemporal_store(c[3 * j + 2] - c[3 * j], gb + o + x);
+                }
+            } else {
+                acc[3 * j] += c[3 * j]; acc[3 * j + 1] += c[3 * j + 1]; acc[3 * j + 2] += c[3 * j + 2];
+            }
+        }
+        if (!BWD) {
+#pragma unroll
+            for (int i = 0; i < 3 * RW; ++i) asm volatile("" : "+v"(acc[i]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!BWD) {
+#pragma unroll
+        for (int j = 0; j < RW; ++j) {
+            const int y = ty0 + wy + 4 * j;
+            if (y < H) {
+                float *orow = gw + (size_t)y * W;
+                orow[x] = acc[3 * j]; (orow + plane)[x] = acc[3 * j + 1]; (orow + 2 * plane)[x] = acc[3 * j + 2];
+            }
+        }
+    }
+}
+template <int LDSB, int RW, bool BWD>
+static void ltmw(const float *w, const float *oy, const float *ox, float *gw, float *ga, float *gb, int H, int W, hipStream_t st)
+{
+    const unsigned tiles_x = (W + 127) / 128, tiles_y = (H + 4 * RW - 1) / (4 * RW);
+    hipLaunchKernelGGL((stream_tapmajor_w<LDSB, RW, BWD>), dim3(((tiles_x * tiles_y + 7) / 8) * 8), dim3(64, 8), 0, st, w, oy, ox, gw, ga, gb, H, W);
+}
+
 // persistent tap-major with a soft global pace-maker: a wave does not start tap t+1 until every
 // wave of its iteration has finished tap t+1-D (bounded spin: purely a performance hint).
 __device__ unsigned g_prog[64 * 25];
@@ -720,6 +800,21 @@ extern "C" int exp_runb(int variant, const float *w, const float *oy, const floa
     case 56: lts<70000, 32, false, 2>(512, w, oy, ox, gw, ga, gb, H, W, st); break;
     case 57: lts<36000, 32, true, 2>(1024, w, oy, ox, gw, ga, gb, H, W, st); break;
     case 58: lts<36000, 32, true, 0>(1024, w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 107: ltmw<88000, 4, false>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 108: ltmw<140000, 4, false>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 109: ltmw<140000, 4, true>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 110: ltmv<88000, 1, 8, false, 7>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 100: ltmv<54000, 1, 4, true, 7>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 101: ltmv<88000, 1, 4, true, 7>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 102: ltmv<88000, 1, 8, true, 7>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 103: ltmv<40000, 1, 4, true, 7>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 104: ltmv<40000, 1, 2, true, 7>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 105: ltmw<88000, 2, true>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 106: ltmw<54000, 2, true>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 95: ltmw<126000, 8, true>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 96: ltmw<88000, 4, true>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 97: ltmw<126000, 8, false>(w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 98: ltmw<72000, 4, true>(w, oy, ox, gw, ga, gb, H, W, st); break;
     case 90: ltmv<54000, 1, 8, true, 11>(w, oy, ox, gw, ga, gb, H, W, st); break;
     case 91: ltmv<54000, 2, 4, true, 11>(w, oy, ox, gw, ga, gb, H, W, st); break;
     case 92: ltmv<54000, 4, 2, true, 11>(w, oy, ox, gw, ga, gb, H, W, st); break;

@@ -20,5 +20,5 @@ for rnd in range(9):
         if rnd: T[v].append(e0.elapsed_time(e1))
 for v in variants:
     med = statistics.median(T[v])
-    nb = 300.0 if v in (90, 91, 92) else 312.0 if v in (35,36,37,38,39,44,45,46,54,55,56,62,63,73,74,83) else 600.0
+    nb = 300.0 if v in (90, 91, 92) else 312.0 if v in (35,36,37,38,39,44,45,46,54,55,56,62,63,73,74,83,97,107,108,110) else 600.0
     print(f"stream variant {v:2d}: {med*1e3:8.1f} us (min {min(T[v])*1e3:8.1f}) {nb*H*W/med/1e6:7.0f} GB/s")
