@@ -16,6 +16,7 @@ from artemis_amd import _lib  # noqa: E402
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     radius = -1
+    padded = "--padded" in sys.argv[1:]
     for a in sys.argv[1:]:
         if a.startswith("--radius="):
             radius = int(a.split("=")[1])
@@ -28,7 +29,9 @@ def main():
     for spec in args:
         B, H, W = map(int, spec.split(","))
         g = torch.Generator(device=dev).manual_seed(1)
-        frames = [torch.rand(B, 3, H, W, device=dev, generator=g) for _ in range(T)]
+        frames = [torch.rand(B, 3, H + (4 if padded else 0), W + (4 if padded else 0), device=dev, generator=g)
+                  for _ in range(T)]
+        fh, fw, org = (H + 4, W + 4, 0) if padded else (H, W, -2)
         w = torch.softmax(torch.randn(B, T, 25, H, W, device=dev, generator=g), 2)
         a = torch.randn(B, T, 25, H, W, device=dev, generator=g)
         b = torch.randn(B, T, 25, H, W, device=dev, generator=g)
@@ -42,25 +45,27 @@ def main():
         def fwd():
             _lib.check(lib.artemis_synth_head_forward(
                 ptrs, T, w.data_ptr(), a.data_ptr(), b.data_ptr(), occ.data_ptr(), out.data_ptr(),
-                B, H, W, H, W, -2, -2, 0, radius, st), "fwd")
+                B, H, W, fh, fw, org, org, 0, radius, st), "fwd")
 
         def bwd():
             _lib.check(lib.artemis_synth_head_backward(
                 ptrs, T, w.data_ptr(), a.data_ptr(), b.data_ptr(), occ.data_ptr(), gout.data_ptr(),
-                gw.data_ptr(), ga.data_ptr(), gb.data_ptr(), gocc.data_ptr(), B, H, W, H, W, -2, -2,
+                gw.data_ptr(), ga.data_ptr(), gb.data_ptr(), gocc.data_ptr(), B, H, W, fh, fw, org, org,
                 0, radius, st), "bwd")
 
         res = {}
         for name, fn, nbytes in (("fwd", fwd, 1276.0), ("bwd", bwd, 2492.0)):
             ts = []
-            for i in range(12):
+            reps = 5  # back-to-back launches per event pair: no idle gap (clock ramp) in the timing
+            for i in range(8):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                fn()
+                for _ in range(reps):
+                    fn()
                 e1.record()
                 e1.synchronize()
                 if i > 1:
-                    ts.append(e0.elapsed_time(e1))
+                    ts.append(e0.elapsed_time(e1) / reps)
             med = statistics.median(ts)
             res[name] = med
             print(f"head B={B} {H}x{W} {name}: {med*1e3:8.1f} us  {nbytes*B*H*W/med/1e6:7.0f} GB/s")
