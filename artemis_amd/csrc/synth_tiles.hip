@@ -41,6 +41,11 @@ struct TileCfg {
     static constexpr int WAVES = SYNTH_WAVES, WX = SYNTH_WX, ROWS = SYNTH_ROWS, OCC = SYNTH_OCC;
     static constexpr bool kSolo = SYNTH_ONE_WG_PER_CU;
 };
+template <>
+struct TileCfg<16> {  // the macros are for experiments at R <= 8; 140 KB at R = 16 leaves no choice
+    static constexpr int WAVES = 8, WX = 2, ROWS = 4, OCC = 2;
+    static constexpr bool kSolo = true;
+};
 
 // Small grids: a problem with fewer than small_grid_tiles() (default 768) tiles of 64 x 32 pixels (the 64^2 and 128^2
 // heads of a small-batch training step, BASELINE configs[0] and [2]) cannot fill 256 CUs and is
