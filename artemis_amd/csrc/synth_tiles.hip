@@ -52,6 +52,21 @@ struct TileCfg<16> {  // the macros are for experiments at R <= 8; 140 KB at R =
 // bound by one workgroup's serial time.  It runs with 64 x 8 tiles instead (4 waves x 2 rows):
 // 4x the workgroups, each a quarter of the work.  Same per-pixel arithmetic, same bits.
 
+// The backward (reads and writes 75 planes each) runs best with still fewer waves in flight: the same
+// 128 x 16 tile by 4 waves (2 across x 2 down, 8 rows each), one workgroup per CU: 242 -> 237 us
+// at 1080p; the forward loses with that shape (108 -> 127 us) and keeps TileCfg.
+#ifndef SYNTH_BWD_WAVES
+#define SYNTH_BWD_WAVES 4
+#endif
+#ifndef SYNTH_BWD_ROWS
+#define SYNTH_BWD_ROWS 8
+#endif
+template <int R>
+struct BwdCfg {
+    static constexpr int WAVES = SYNTH_BWD_WAVES, WX = 2, ROWS = SYNTH_BWD_ROWS, OCC = 2;
+    static constexpr bool kSolo = true;
+};
+
 struct SmallCfg {
     static constexpr int WAVES = 4, WX = 1, ROWS = 2, OCC = 2;
     static constexpr bool kSolo = false;
@@ -137,7 +152,7 @@ void launch_bwd_tiled(const FT *in, const float *w, const float *oy, const float
     if (small_grid<TileCfg<R>>(g, true))
         bwd_cfg<R, SmallCfg, FT>(false, in, w, oy, ox, gout, gw, goy, gox, g, HeadArgs{}, st);
     else
-        bwd_cfg<R, TileCfg<R>, FT>(false, in, w, oy, ox, gout, gw, goy, gox, g, HeadArgs{}, st);
+        bwd_cfg<R, BwdCfg<R>, FT>(false, in, w, oy, ox, gout, gw, goy, gox, g, HeadArgs{}, st);
 }
 
 template <int R, class FT>
@@ -155,7 +170,7 @@ void launch_head_bwd(const float *w, const float *oy, const float *ox, const flo
     if (small_grid<TileCfg<R>>(g, true))
         bwd_cfg<R, SmallCfg, FT>(true, (const FT *)nullptr, w, oy, ox, gout, gw, goy, gox, g, ha, st);
     else
-        bwd_cfg<R, TileCfg<R>, FT>(true, (const FT *)nullptr, w, oy, ox, gout, gw, goy, gox, g, ha, st);
+        bwd_cfg<R, BwdCfg<R>, FT>(true, (const FT *)nullptr, w, oy, ox, gout, gw, goy, gox, g, ha, st);
 }
 
 // gradInput tiles: 64 x 16 pixels, 64-bit accumulators (3 x 29 x 77 x 8 B = 53.6 KB at R = 4,
