@@ -309,7 +309,7 @@ def main():
         }
         if world == 1 and not args.no_head:
             line["config"]["chrono_head_fwd_bwd_1080p"] = head_timing(device, args.radius, args.sigma)
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:  # reported at N = 1 only
             threads = args.cpu_threads or min(16, os.cpu_count() or 1)
             line["cpu_baseline"] = cpu_baseline(threads, args.sigma)
         print(json.dumps(line))
