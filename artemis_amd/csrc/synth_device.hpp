@@ -1427,7 +1427,8 @@ __global__ __launch_bounds__(256) void offset_radius_kernel(const float *__restr
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+    // only when it can raise the running maximum (same-address atomics serialise, see absmax2_kernel)
+    if ((threadIdx.x & 63) == 0 && m > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, m);
 }
 
 }  // namespace
