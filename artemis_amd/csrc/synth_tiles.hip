@@ -41,9 +41,12 @@ struct TileCfg {
     static constexpr int WAVES = SYNTH_WAVES, WX = SYNTH_WX, ROWS = SYNTH_ROWS, OCC = SYNTH_OCC;
     static constexpr bool kSolo = SYNTH_ONE_WG_PER_CU;
 };
+#ifndef SYNTH_R16_WX
+#define SYNTH_R16_WX 2
+#endif
 template <>
-struct TileCfg<16> {  // the macros are for experiments at R <= 8; 140 KB at R = 16 leaves no choice
-    static constexpr int WAVES = 8, WX = 2, ROWS = 4, OCC = 2;
+struct TileCfg<16> {  // the macros above are for experiments at R <= 8
+    static constexpr int WAVES = 8, WX = SYNTH_R16_WX, ROWS = 4, OCC = 2;
     static constexpr bool kSolo = true;
 };
 
@@ -63,7 +66,8 @@ struct TileCfg<16> {  // the macros are for experiments at R <= 8; 140 KB at R =
 #endif
 template <int R>
 struct BwdCfg {
-    static constexpr int WAVES = SYNTH_BWD_WAVES, WX = 2, ROWS = SYNTH_BWD_ROWS, OCC = 2;
+    static constexpr int WAVES = SYNTH_BWD_WAVES, WX = R == 16 ? SYNTH_R16_WX : 2, ROWS = SYNTH_BWD_ROWS,
+                         OCC = 2;
     static constexpr bool kSolo = true;
 };
 
