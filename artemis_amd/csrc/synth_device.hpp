@@ -426,7 +426,9 @@ __device__ __forceinline__ int det_scale_log2(const unsigned *hdr, int count_bit
     if (!(m > 0.f) || !(m < 3.0e38f)) return 0;
     int e;
     frexpf(m, &e);  // m < 2^e
-    return min(30, 62 - count_bits) - e;
+    // 2^S and 2^-S must both be finite, normal fp32 numbers (tiny gradients times tiny weights
+    // would otherwise ask for S > 127: scale = inf, every contribution saturates)
+    return max(-126, min(126, min(30, 62 - count_bits) - e));
 }
 
 __device__ __forceinline__ unsigned long long to_fixed(float contrib_scaled)
@@ -1004,8 +1006,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < ROWS; ++j) {
-                float wv = cur.w[j];
-                const float a = cur.a[j], b = cur.b[j];
+                const float wv = cur.w[j], a = cur.a[j], b = cur.b[j];
                 const int ia = (int)a, ib = (int)b;
                 const float fa = a - (float)ia, fb = b - (float)ib;
                 const float reach = fmaxf(fabsf((float)ia - ctr.y), fabsf((float)ib - ctr.x));
@@ -1013,10 +1014,16 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
                 const Corners q = tile_corners_at<R, TH, r * LW + s, TW>(ltile, ia, ib, rowbase[j] - cbase);
                 const float ga = 1.f - fa, gb = 1.f - fb;
                 const float c00 = ga * gb, c10 = fa * gb, c01 = ga * fb, c11 = fa * fb;
-                wv = reach <= (float)R ? wv : 0.f;  // a far tap is added by the fix-up instead
-                acc0[j] += wv * (q.bl.x * c00 + q.tl.x * c10 + q.br.x * c01 + q.tr.x * c11);
-                acc1[j] += wv * (q.bl.y * c00 + q.tl.y * c10 + q.br.y * c01 + q.tr.y * c11);
-                acc2[j] += wv * (q.bl.z * c00 + q.tl.z * c10 + q.br.z * c01 + q.tr.z * c11);
+                // A far tap is added by the fix-up instead.  Its term is dropped by a select, not by
+                // a zero weight: the clamped LDS address of a far tap points at an unrelated texel,
+                // and 0 * Inf / 0 * NaN from there would poison a pixel the reference leaves finite.
+                const bool near = reach <= (float)R;
+                const float n0 = acc0[j] + wv * (q.bl.x * c00 + q.tl.x * c10 + q.br.x * c01 + q.tr.x * c11);
+                const float n1 = acc1[j] + wv * (q.bl.y * c00 + q.tl.y * c10 + q.br.y * c01 + q.tr.y * c11);
+                const float n2 = acc2[j] + wv * (q.bl.z * c00 + q.tl.z * c10 + q.br.z * c01 + q.tr.z * c11);
+                acc0[j] = near ? n0 : acc0[j];
+                acc1[j] = near ? n1 : acc1[j];
+                acc2[j] = near ? n2 : acc2[j];
                 // Pin the arithmetic in place: instruction selection otherwise floats the
                 // chain-free FMAs to the end of the unrolled block, keeping every LDS result of
                 // the pixel live (512 VGPRs or spills).  The sched_barrier bounds the LDS results
@@ -1190,7 +1197,10 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
                     const float gar = wv * (dl + fb * (dr - dl));
                     const float gbr = wv * across;
                     // a far tap's share comes from the fix-up, which also overwrites its stores
-                    gocc[j] += (reach <= (float)R ? wv : 0.f) * gwr;
+                    // (a select of the product: 0 * NaN from a far tap's unrelated texel must not
+                    // enter the sum)
+                    const float ng = gocc[j] + wv * gwr;
+                    gocc[j] = reach <= (float)R ? ng : gocc[j];
                     if (ALL || gw) st_stream(gw + o + (unsigned)x, occv[j] * gwr);
                     if (ALL || goy) st_stream(goy + o + (unsigned)x, occv[j] * gar);
                     if (ALL || gox) st_stream(gox + o + (unsigned)x, occv[j] * gbr);

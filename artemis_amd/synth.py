@@ -105,6 +105,13 @@ def _frame_dtype(t):
     raise TypeError(f"frames must be float32 or bfloat16, got {t.dtype}")
 
 
+def _capture_options(context):
+    """The options in force when the forward runs also govern its backward: autograd calls
+    backward later, on its own thread, usually outside any ``with synth_options(...)`` block."""
+    context.synth_tile_radius = int(options.tile_radius)
+    context.synth_deterministic = bool(options.deterministic)
+
+
 def _launch_forward(input, weight, offset_y, offset_x, dilation, geom):
     """geom = (N, C, H, W, k, in_H, in_W, org_y, org_x)"""
     N, C, H, W, k, Hin, Win, oy0, ox0 = geom
@@ -120,8 +127,12 @@ def _launch_forward(input, weight, offset_y, offset_x, dilation, geom):
     return output
 
 
-def _launch_backward(need, gradOutput, input, weight, offset_y, offset_x, dilation, geom):
+def _launch_backward(need, gradOutput, input, weight, offset_y, offset_x, dilation, geom,
+                     tile_radius=None, deterministic=None):
+    """tile_radius / deterministic: the values captured at forward time (None: current options)."""
     N, C, H, W, k, Hin, Win, oy0, ox0 = geom
+    tile_radius = int(options.tile_radius if tile_radius is None else tile_radius)
+    deterministic = bool(options.deterministic if deterministic is None else deterministic)
     assert (gradOutput.is_contiguous() == True)
     if not input.is_cuda:
         raise NotImplementedError()
@@ -136,7 +147,7 @@ def _launch_backward(need, gradOutput, input, weight, offset_y, offset_x, dilati
         gradOffset_y = weight.new_empty(N, k * k, H, W) if need[2] else None
         gradOffset_x = weight.new_empty(N, k * k, H, W) if need[3] else None
 
-        deterministic = options.deterministic or torch.are_deterministic_algorithms_enabled()
+        deterministic = deterministic or torch.are_deterministic_algorithms_enabled()
         mode = _lib.GIN_DETERMINISTIC if deterministic else _lib.GIN_ATOMIC
         workspace, ws_bytes = None, 0
         if need[0]:
@@ -150,7 +161,7 @@ def _launch_backward(need, gradOutput, input, weight, offset_y, offset_x, dilati
                 _ptr(input), _ptr(weight), _ptr(offset_y), _ptr(offset_x), _ptr(gradOutput),
                 _ptr(gradInput), _ptr(gradWeight), _ptr(gradOffset_y), _ptr(gradOffset_x),
                 N, C, H, W, k, int(dilation), Hin, Win, oy0, ox0, _frame_dtype(input), mode,
-                int(options.tile_radius), _ptr(workspace), ws_bytes, stream),
+                tile_radius, _ptr(workspace), ws_bytes, stream),
                 "artemis_synth_backward")
         if gradInput is not None and gradInput.dtype != input.dtype:
             gradInput = gradInput.to(input.dtype)   # autograd wants the frame's dtype
@@ -162,6 +173,7 @@ class FunctionSynth(torch.autograd.Function):
     def forward(context, input, weight, offset_y, offset_x, dilation):
         context.save_for_backward(input, weight, offset_y, offset_x)
         context.dilation = dilation
+        _capture_options(context)
 
         _check_operands(input, weight, offset_y, offset_x)
         N, C, H, W, k, Hin, Win = _dims(input, weight, dilation)
@@ -183,7 +195,8 @@ class FunctionSynth(torch.autograd.Function):
         dilation = context.dilation
         N, C, H, W, k, Hin, Win = _dims(input, weight, dilation)
         grads = _launch_backward(context.needs_input_grad, gradOutput, input, weight, offset_y,
-                                 offset_x, dilation, (N, C, H, W, k, Hin, Win, 0, 0))
+                                 offset_x, dilation, (N, C, H, W, k, Hin, Win, 0, 0),
+                                 context.synth_tile_radius, context.synth_deterministic)
         return (*grads, None)
 
 
@@ -197,6 +210,7 @@ class FunctionSynthFrame(torch.autograd.Function):
     @staticmethod
     def forward(context, frame, weight, offset_y, offset_x, dilation, origin_y, origin_x):
         context.save_for_backward(frame, weight, offset_y, offset_x)
+        _capture_options(context)
         _check_operands(frame, weight, offset_y, offset_x, bf16_frame_ok=True)
         k = int(math.sqrt(weight.size(1)))
         assert k * k == weight.size(1), "weight.size(1) must be a square"
@@ -213,7 +227,8 @@ class FunctionSynthFrame(torch.autograd.Function):
     def backward(context, gradOutput):
         frame, weight, offset_y, offset_x = context.saved_tensors
         grads = _launch_backward(context.needs_input_grad, gradOutput, frame, weight, offset_y,
-                                 offset_x, context.dilation, context.geom)
+                                 offset_x, context.dilation, context.geom,
+                                 context.synth_tile_radius, context.synth_deterministic)
         return (*grads, None, None, None)
 
 
@@ -292,6 +307,7 @@ class FunctionChronoHead(torch.autograd.Function):
             raise NotImplementedError()
 
         context.save_for_backward(weights, alphas, betas, occlusion, *frames)
+        _capture_options(context)
         context.geom = (B, T, H, W, H + 2 * pad, W + 2 * pad, pad - 2, fdt)
         lib = _lib.load()
         with torch.cuda.device(weights.device):
@@ -322,7 +338,7 @@ class FunctionChronoHead(torch.autograd.Function):
                 _lib.check(lib.artemis_synth_head_backward(
                     ptrs, T, _ptr(weights), _ptr(alphas), _ptr(betas), _ptr(occlusion),
                     _ptr(gradOutput), _ptr(gw), _ptr(ga), _ptr(gb), _ptr(gocc), B, H, W, Hin, Win,
-                    org, org, fdt, int(options.tile_radius),
+                    org, org, fdt, context.synth_tile_radius,
                     torch.cuda.current_stream().cuda_stream), "artemis_synth_head_backward")
             # Frame gradients (ArTEMIS never asks for them: its frames are inputs) are not part of
             # the fused kernel: per frame, gradInput of the op for gradOutput * occ_f.
@@ -334,7 +350,8 @@ class FunctionChronoHead(torch.autograd.Function):
                 gframes[f] = _launch_backward(
                     (True, False, False, False), gs, frames[f], weights[:, f].contiguous(),
                     alphas[:, f].contiguous(), betas[:, f].contiguous(), 1,
-                    (B, 3, H, W, 5, Hin, Win, org, org))[0]
+                    (B, 3, H, W, 5, Hin, Win, org, org),
+                    context.synth_tile_radius, context.synth_deterministic)[0]
         return (gw, ga, gb, gocc, None, *gframes)
 
 

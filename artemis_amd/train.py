@@ -1,7 +1,8 @@
 """A Lightning-free training step around the synthesis head: ChronoSynth (this package's
 restatement, fused head op) + L1 loss + Adamax + MultiStepLR, one process per GPU with
 ``torch.distributed`` -- the pieces of the reference's ``main.py`` that touch the hot path
-(``main.py:45`` Adamax, ``:93`` MultiStepLR(gamma 0.5), ``loss.py:9`` L1; Lightning DDP ``:135``).
+(``main.py:45`` Adamax, ``:89-93`` MultiStepLR([40,60,75,85,95,100], gamma 0.5) stepped per epoch,
+``loss.py:9`` L1; Lightning DDP ``:133``).
 
 The op itself needs no collective: the batch is sharded over ranks (``sharding.shard_batch``) and
 the only exchange of a step is DDP's gradient all-reduce of the module's parameters (RCCL over
@@ -37,7 +38,11 @@ def synthetic_batch(batch, num_features, size, seed, device):
 class HeadTrainer:
     """One ChronoSynth head under Adamax + MultiStepLR, data-parallel over the process group."""
 
-    def __init__(self, device, num_features=64, lr=2e-4, betas=(0.9, 0.999), milestones=(100, 150),
+    #: main.py:89 -- MultiStepLR milestones, counted in EPOCHS (Lightning steps the scheduler once
+    #: per epoch by default), gamma 0.5 (:93)
+    MILESTONES = (40, 60, 75, 85, 95, 100)
+
+    def __init__(self, device, num_features=64, lr=2e-4, betas=(0.9, 0.999), milestones=MILESTONES,
                  seed=103, fused=True):
         torch.manual_seed(seed)          # config.py:62; same init on every rank
         self.device = device
@@ -53,8 +58,13 @@ class HeadTrainer:
         self.loss = nn.L1Loss(reduction="mean")
 
     def shard(self, batch):
-        """This rank's slice of a global batch (features, frames, gt, times)."""
+        """This rank's slice of a global batch (features, frames, gt, times).  The batch must
+        divide evenly: DDP averages the per-rank mean losses' gradients, which is the global mean
+        only for equal shards (and an empty shard would make the L1 mean NaN)."""
         feats, frames, gt, t = batch
+        if feats.size(0) % self.world != 0:
+            raise ValueError(f"global batch {feats.size(0)} is not a multiple of the world size "
+                             f"{self.world}: DDP's gradient average would not be the global mean")
         b, e = shard_bounds(feats.size(0), self.rank, self.world)
         return feats[b:e], [f[b:e] for f in frames], gt[b:e], t[b:e]
 
@@ -65,14 +75,18 @@ class HeadTrainer:
         loss = self.loss(out, gt)
         loss.backward()                  # DDP all-reduces (averages) the parameter gradients here
         self.optimizer.step()
-        self.scheduler.step()
         return loss.detach()
+
+    def end_epoch(self):
+        """Step the LR schedule: once per epoch, as Lightning does for main.py:89-95."""
+        self.scheduler.step()
 
 
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     add_device_argument(ap)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=3, help="optimizer steps per epoch")
+    ap.add_argument("--epochs", type=int, default=1)
     ap.add_argument("--batch", type=int, default=8, help="global batch (sharded over ranks)")
     ap.add_argument("--size", type=int, default=64)
     ap.add_argument("--features", type=int, default=64)
@@ -90,9 +104,11 @@ def main(argv=None):
         kw = {"device_id": device} if args.backend == "nccl" else {}
         torch.distributed.init_process_group(args.backend, **kw)
     tr = HeadTrainer(device, num_features=args.features, fused=not args.composed)
-    for i in range(args.steps):
+    for i in range(args.steps * args.epochs):
         batch = synthetic_batch(args.batch, args.features, (args.size, args.size), 1000 + i, device)
         loss = tr.step(batch)
+        if (i + 1) % args.steps == 0:
+            tr.end_epoch()
         if world > 1:
             torch.distributed.all_reduce(loss, op=torch.distributed.ReduceOp.AVG
                                          if args.backend == "nccl" else torch.distributed.ReduceOp.SUM)

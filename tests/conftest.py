@@ -66,3 +66,104 @@ def make_operands(N, C, H, W, k=5, d=1, regime="gauss1", seed=0, weights="softma
         raise KeyError(regime)
     gout = rng.standard_normal((N, C, H, W), dtype=np.float32)
     return inp, weight, oy, ox, gout
+
+
+# ---------------------------------------------------------------------------------------------
+# Parity comparison shared by the GPU tests, with a record of the worst observed errors.
+#
+# Contract (BASELINE.json north_star): forward within 1e-5 relative, backward within 1e-4.  Two
+# asserts per tensor:
+#   (1) norm-relative:   |hip - oracle| <= rtol * (|oracle| + max(max|oracle|, floor)) everywhere;
+#   (2) elementwise-relative: |hip - oracle| <= rtol * |oracle| on every element with
+#       |oracle| >= elem_floor(rtol) * max|oracle|.
+# Both sides are fp32 sums of up to 100 products in different association (the device contracts
+# a*b+c to FMAs), so they differ by a few ulp of the LARGEST partial sum -- observed worst
+# 3.0e-7 * max|oracle| over every GPU test (profiles/parity_errors.txt) -- whatever the size of the
+# element itself.  An elementwise relative bound of rtol can therefore only be asked of elements
+# of at least ~5e-7 / rtol of the tensor's scale: 0.05 * max for the forward's 1e-5, 0.005 * max for
+# the backward's 1e-4; smaller elements are cancelling sums whose error (1) bounds in absolute
+# terms.  The worst elementwise error on the wider set |oracle| >= 1e-3 * max is recorded too.
+# Worst observed errors are printed in the terminal summary and written to
+# gpurun_out/parity_errors.txt (tracked copy: profiles/parity_errors.txt).
+WIDE_FLOOR_FRAC = 1e-3
+ELEM_ASSERT = os.environ.get("PARITY_ELEMWISE", "assert") != "record"
+
+
+def elem_floor(rtol):
+    return min(0.5, 5e-7 / rtol)
+
+
+_parity_worst = {}   # (module, tensor name, rtol) -> [worst norm-rel, worst elem-rel, count]
+
+
+def _caller_module():
+    import inspect
+    for fr in inspect.stack()[2:]:
+        name = os.path.basename(fr.filename)
+        if name.startswith("test_") or name.startswith("wip_"):
+            return name[:-3]
+    return "?"
+
+
+def parity_close(actual, desired, rtol, what="", floor=1e-30, elementwise=True):
+    import torch
+    if torch.is_tensor(actual):
+        actual = actual.detach().float().cpu().numpy()
+    if torch.is_tensor(desired):
+        desired = desired.detach().float().cpu().numpy()
+    scale = float(np.abs(desired[np.isfinite(desired)]).max()) if np.isfinite(desired).any() else 0.0
+    np.testing.assert_allclose(actual, desired, rtol=rtol, atol=rtol * max(scale, floor),
+                               err_msg=what)
+    fin = np.isfinite(desired) & np.isfinite(actual)
+    if not fin.any():
+        return
+    d = np.abs(desired[fin].astype(np.float64))
+    err = np.abs(actual[fin].astype(np.float64) - desired[fin].astype(np.float64))
+    ref = max(scale, floor)
+    norm_rel = float(err.max()) / ref
+
+    def worst(frac):
+        big = d >= frac * ref
+        return float((err[big] / d[big]).max()) if big.any() else 0.0
+
+    elem_rel, wide_rel = worst(elem_floor(rtol)), worst(WIDE_FLOOR_FRAC)
+    name = (what.split(",")[0].strip() or "tensor")
+    rec = _parity_worst.setdefault((_caller_module(), name, rtol), [0.0, 0.0, 0.0, 0])
+    rec[0] = max(rec[0], norm_rel)
+    rec[1] = max(rec[1], elem_rel)
+    rec[2] = max(rec[2], wide_rel)
+    rec[3] += 1
+    if elementwise and ELEM_ASSERT:
+        assert elem_rel <= rtol, (
+            f"{what}: worst elementwise relative error {elem_rel:.3e} on elements >= "
+            f"{elem_floor(rtol):g} * max|oracle| exceeds {rtol:g}")
+
+
+def _parity_report_lines():
+    lines = ["# worst observed parity errors (HIP vs oracle; oracle vs its second restatement in the "
+             "CPU tests), per test module and tensor",
+             "# norm_rel = max|a-b| / max|b| ; elem_rel = max |a-b|/|b| over elements with |b| >= "
+             "(5e-7/rtol) * max|b| (asserted <= rtol) ; wide_rel = the same over |b| >= %g * max|b| "
+             "(recorded)" % WIDE_FLOOR_FRAC,
+             "%-26s %-30s %6s %10s %10s %10s %6s" % ("module", "tensor", "rtol", "norm_rel",
+                                                     "elem_rel", "wide_rel", "checks")]
+    for (mod, name, rtol), (nr, er, wr, cnt) in sorted(_parity_worst.items()):
+        lines.append("%-26s %-30s %6.0e %10.2e %10.2e %10.2e %6d" % (mod, name[:30], rtol, nr, er, wr,
+                                                                     cnt))
+    return lines
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    if not _parity_worst:
+        return
+    lines = _parity_report_lines()
+    terminalreporter.write_sep("-", "parity errors (worst per tensor)")
+    for ln in lines:
+        terminalreporter.write_line(ln)
+    try:
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_errors.txt"), "w") as f:
+            f.write("\n".join(lines) + "\n")
+    except OSError:
+        pass

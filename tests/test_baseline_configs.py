@@ -1,0 +1,202 @@
+"""BASELINE.json configs[2], [3], [4] at their STATED sizes on the GPU against the CPU oracle.
+
+* configs[3] "Interpolate mode at 1080p, one 4-frame window, 7 timesteps batched as one launch":
+  the op and the fused head at N = 7 x 1080 x 1920 in one launch (main.py:114-121 runs the
+  timesteps one by one; batching them is this build's addition).  Samples 0 and 6
+  in full against the oracle; all 7 against their own N = 1 launches, bit for bit.
+* configs[2] "train step on 256x256 crops, batch 64": the three heads (64 | 8, 25, {64,128,256}^2)
+  forward + backward (model/chrono_synth.py:109-127 shapes; 8 = one rank's shard of 64 on 8 GPUs),
+  incl. the small-grid 64 x 8 tile path; a sample subset against oracle.backward.
+* configs[4] "4K with bf16 frames, spatial tiles sharded over 8 GPUs": 270-row bf16 strips of the
+  3840 x 2160 frame against oracle.forward_ex / backward_ex on the rounded frame.
+
+Operands are generated on the device (seeded) and only the compared samples travel to the host.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import parity_close
+
+pytestmark = pytest.mark.gpu
+
+FWD_RTOL = 1e-5
+BWD_RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import artemis_amd
+    artemis_amd._lib.load()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def fast_oracle(oracle):
+    import os
+    oracle.set_threads(min(16, os.cpu_count() or 1))
+    yield oracle
+    oracle.set_threads(1)
+
+
+def np_(t):
+    return np.ascontiguousarray(t.detach().float().cpu().numpy())
+
+
+# ------------------------------------------------------------------ configs[3]: N = 7 x 1080p
+
+def test_config3_op_seven_timesteps_one_launch(dev, fast_oracle):
+    import artemis_amd
+    g = torch.Generator(device=dev).manual_seed(3)
+    N, H, W = 7, 1080, 1920
+    # one 4-frame window: the same frame for every timestep, different weights/offsets per timestep
+    frame = torch.rand(1, 3, H, W, device=dev, generator=g)
+    inp = torch.nn.functional.pad(frame, (2,) * 4, mode="replicate").expand(N, 3, H + 4, W + 4).contiguous()
+    w = torch.softmax(torch.randn(N, 25, H, W, device=dev, generator=g), 1)
+    oy = torch.randn(N, 25, H, W, device=dev, generator=g) * 1.5
+    ox = torch.randn(N, 25, H, W, device=dev, generator=g) * 1.5
+    out = artemis_amd.synth(inp, w, oy, ox, 1)          # ONE launch for the 7 timesteps
+    torch.cuda.synchronize()
+    assert out.shape == (N, 3, H, W)
+    for n in range(N):                                   # every sample: the bits of its own launch
+        one = artemis_amd.synth(inp[n:n + 1], w[n:n + 1].contiguous(), oy[n:n + 1].contiguous(),
+                                ox[n:n + 1].contiguous(), 1)
+        assert torch.equal(out[n:n + 1], one), f"timestep {n}"
+    for n in (0, 6):                                     # first and last in full against the oracle
+        ref = fast_oracle.forward(np_(inp[n:n + 1]), np_(w[n:n + 1]), np_(oy[n:n + 1]),
+                                  np_(ox[n:n + 1]), 1)
+        parity_close(out[n:n + 1], ref, FWD_RTOL, f"config3 op output, timestep {n}")
+
+
+def test_config3_head_seven_timesteps_one_launch(dev, fast_oracle):
+    import artemis_amd
+    g = torch.Generator(device=dev).manual_seed(4)
+    B, T, H, W = 7, 4, 1080, 1920
+    frames1 = [torch.rand(1, 3, H, W, device=dev, generator=g) for _ in range(T)]
+    frames = [f.expand(B, 3, H, W).contiguous() for f in frames1]
+    w = torch.softmax(torch.randn(B, T, 25, H, W, device=dev, generator=g), 2)
+    a = torch.randn(B, T, 25, H, W, device=dev, generator=g)
+    b = torch.randn(B, T, 25, H, W, device=dev, generator=g)
+    occ = torch.softmax(torch.randn(B, T, H, W, device=dev, generator=g), 1)
+    out = artemis_amd.chrono_head(frames, w, a, b, occ)  # ONE launch: 7 timesteps x 4 frames
+    torch.cuda.synchronize()
+    for n in range(B):
+        one = artemis_amd.chrono_head(frames1, w[n:n + 1].contiguous(), a[n:n + 1].contiguous(),
+                                      b[n:n + 1].contiguous(), occ[n:n + 1].contiguous())
+        assert torch.equal(out[n:n + 1], one), f"timestep {n}"
+    f_np = [np_(f) for f in frames1]
+    for n in (0, 6):
+        ref, _ = fast_oracle.head_forward(f_np, np_(w[n:n + 1]), np_(a[n:n + 1]), np_(b[n:n + 1]),
+                                          np_(occ[n:n + 1]), 1)
+        parity_close(out[n:n + 1], ref, FWD_RTOL, f"config3 head output, timestep {n}")
+
+
+# ------------------------------------------------------------------ configs[2]: batch-64 train heads
+
+def head_case(dev, B, hw, seed, sigma):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    T = 4
+    frames = [torch.rand(B, 3, hw, hw, device=dev, generator=g) for _ in range(T)]
+    w = torch.softmax(torch.randn(B, T, 25, hw, hw, device=dev, generator=g), 2)
+    a = torch.randn(B, T, 25, hw, hw, device=dev, generator=g) * sigma
+    b = torch.randn(B, T, 25, hw, hw, device=dev, generator=g) * sigma
+    occ = torch.softmax(torch.randn(B, T, hw, hw, device=dev, generator=g), 1)
+    gout = torch.randn(B, 3, hw, hw, device=dev, generator=g)
+    return frames, w, a, b, occ, gout
+
+
+@pytest.mark.parametrize("B,hw,samples", [(8, 64, range(8)), (8, 128, (0, 3, 7)), (8, 256, (0, 7)),
+                                          (64, 64, (0, 31, 63)), (64, 128, (63,)), (64, 256, (17,))])
+def test_config2_train_heads_forward_backward(dev, fast_oracle, B, hw, samples):
+    """The fused head (what artemis_amd.model.ChronoSynth runs in the train step) and, for the
+    same operands, the per-frame op of frame 1, forward + backward, against the oracle."""
+    import artemis_amd
+    frames, w, a, b, occ, gout = head_case(dev, B, hw, seed=B * 1000 + hw, sigma=1.0)
+    t = [x.clone().requires_grad_(True) for x in (w, a, b, occ)]
+    out = artemis_amd.chrono_head(frames, *t)
+    out.backward(gout)
+    # per-frame op (FunctionSynth on the padded frame), as the reference composes it
+    f = 1
+    padded = torch.nn.functional.pad(frames[f], (2,) * 4, mode="replicate").requires_grad_(True)
+    opw = [x[:, f].contiguous().requires_grad_(True) for x in (w, a, b)]
+    oout = artemis_amd.FunctionSynth.apply(padded, *opw, 1)
+    oout.backward(gout)
+    torch.cuda.synchronize()
+    for n in samples:
+        sl = slice(n, n + 1)
+        f_np = [np_(x[sl]) for x in frames]
+        args = (np_(w[sl]), np_(a[sl]), np_(b[sl]), np_(occ[sl]))
+        ref, _ = fast_oracle.head_forward(f_np, *args, 1)
+        parity_close(out[sl], ref, FWD_RTOL, f"config2 head output B{B} {hw}^2")
+        rgw, rga, rgb, rgocc = fast_oracle.head_backward(np_(gout[sl]), f_np, *args, 1)
+        term = float(gout[sl].abs().max() * w[sl].abs().max())
+        parity_close(t[0].grad[sl], rgw, BWD_RTOL, "config2 head grad_weights")
+        parity_close(t[1].grad[sl], rga, BWD_RTOL, "config2 head grad_alphas", term)
+        parity_close(t[2].grad[sl], rgb, BWD_RTOL, "config2 head grad_betas", term)
+        parity_close(t[3].grad[sl], rgocc, BWD_RTOL, "config2 head grad_occlusion")
+        # the op
+        pin = np_(padded[sl])
+        wa = [np_(x[sl]) for x in opw]
+        parity_close(oout[sl], fast_oracle.forward(pin, *wa, 1), FWD_RTOL, f"config2 op output B{B} {hw}^2")
+        rgi, ogw, oga, ogb = fast_oracle.backward(np_(gout[sl]), pin, *wa, 1)
+        parity_close(opw[0].grad[sl], ogw, BWD_RTOL, "config2 op grad_weight")
+        parity_close(opw[1].grad[sl], oga, BWD_RTOL, "config2 op grad_offset_y", term)
+        parity_close(opw[2].grad[sl], ogb, BWD_RTOL, "config2 op grad_offset_x", term)
+        parity_close(padded.grad[sl], rgi, BWD_RTOL, "config2 op grad_input")
+
+
+def test_config2_small_grid_path_is_taken_and_bit_identical(dev):
+    """B = 8 at 64^2 is 16 tiles of 64 x 32: far below the small-grid knob, so the 64 x 8 tile
+    kernels run; forcing the big tiles (knob 0) must give the same bits."""
+    import artemis_amd
+    from artemis_amd import _lib
+    lib = _lib.load()
+    frames, w, a, b, occ, gout = head_case(dev, 8, 64, seed=77, sigma=1.0)
+    res = []
+    old = lib.artemis_synth_set_small_grid_tiles(-1)
+    try:
+        for knob in (old, 0):
+            lib.artemis_synth_set_small_grid_tiles(knob)
+            t = [x.clone().requires_grad_(True) for x in (w, a, b, occ)]
+            out = artemis_amd.chrono_head(frames, *t)
+            out.backward(gout)
+            torch.cuda.synchronize()
+            res.append([out.detach()] + [x.grad for x in t])
+    finally:
+        lib.artemis_synth_set_small_grid_tiles(old)
+    assert old > 16 * 4
+    for x, y in zip(*res):
+        assert torch.equal(x, y)
+
+
+# ------------------------------------------------------------------ configs[4]: 4K bf16 strips
+
+@pytest.mark.parametrize("strip", [0, 3, 7])
+def test_config4_4k_bf16_strip_against_oracle(dev, fast_oracle, strip):
+    import artemis_amd
+    from artemis_amd.sharding import row_strips
+    g = torch.Generator(device=dev).manual_seed(40 + strip)
+    H, W = 2160, 3840
+    y0, y1 = row_strips(H, 8, halo=0)[strip][:2]
+    assert y1 - y0 == 270
+    frame = torch.rand(1, 3, H, W, device=dev, generator=g).to(torch.bfloat16)
+    h = y1 - y0
+    w = torch.softmax(torch.randn(1, 25, h, W, device=dev, generator=g), 1).requires_grad_(True)
+    oy = (torch.randn(1, 25, h, W, device=dev, generator=g) * 2).requires_grad_(True)
+    ox = (torch.randn(1, 25, h, W, device=dev, generator=g) * 2).requires_grad_(True)
+    gout = torch.randn(1, 3, h, W, device=dev, generator=g)
+    out = artemis_amd.synth_strip(frame, w, oy, ox, y0, 1, padded=False)
+    out.backward(gout)
+    torch.cuda.synchronize()
+    assert out.dtype == torch.float32
+    rounded = np_(frame)                                  # the bf16 frame widened exactly
+    org = (y0 - 2, -2)
+    ref = fast_oracle.forward_ex(rounded, np_(w), np_(oy), np_(ox), 1, origin=org)
+    parity_close(out, ref, FWD_RTOL, f"config4 strip output")
+    _, rgw, rga, rgb = fast_oracle.backward_ex(np_(gout), rounded, np_(w), np_(oy), np_(ox), 1,
+                                               origin=org, with_input=False)
+    term = float(gout.abs().max() * w.abs().max())
+    parity_close(w.grad, rgw, BWD_RTOL, "config4 strip grad_weight")
+    parity_close(oy.grad, rga, BWD_RTOL, "config4 strip grad_offset_y", term)
+    parity_close(ox.grad, rgb, BWD_RTOL, "config4 strip grad_offset_x", term)

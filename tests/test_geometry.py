@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import make_operands
+from conftest import make_operands, parity_close
 
 FWD_RTOL = 1e-5
 BWD_RTOL = 1e-4
@@ -96,12 +96,8 @@ def dev():
 
 
 def close(actual, desired, rtol, what="", floor=1e-30):
-    """|actual - desired| <= rtol * (|desired| + max(max|desired|, floor)).  `floor` is the size of
-    the terms that are summed: when they cancel (a frame of one texel has zero offset gradient)
-    the oracle's own value is only round-off of that size."""
-    actual = actual.detach().cpu().numpy() if torch.is_tensor(actual) else actual
-    scale = float(np.abs(desired).max()) if desired.size else 0.0
-    np.testing.assert_allclose(actual, desired, rtol=rtol, atol=rtol * max(scale, floor), err_msg=what)
+    """conftest.parity_close: norm-relative and elementwise-relative asserts, worst errors recorded."""
+    parity_close(actual, desired, rtol, what, floor)
 
 
 def term_size(frame, w, gout):

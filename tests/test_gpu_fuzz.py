@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import make_operands
+from conftest import make_operands, parity_close
 
 pytestmark = pytest.mark.gpu
 
@@ -21,9 +21,8 @@ def dev():
 
 
 def close(actual, desired, rtol, what="", floor=1e-30):
-    actual = actual.detach().cpu().numpy() if torch.is_tensor(actual) else actual
-    scale = float(np.abs(desired).max()) if desired.size else 0.0
-    np.testing.assert_allclose(actual, desired, rtol=rtol, atol=rtol * max(scale, floor), err_msg=what)
+    """conftest.parity_close: norm-relative and elementwise-relative asserts, worst errors recorded."""
+    parity_close(actual, desired, rtol, what, floor)
 
 
 REGIMES = ["init", "gauss1", "gauss4", "uniform3", "clamp40", "integer", "zero"]

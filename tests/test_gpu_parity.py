@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden_names, load_golden, make_operands
+from conftest import golden_names, load_golden, make_operands, parity_close
 
 pytestmark = pytest.mark.gpu
 
@@ -31,10 +31,8 @@ def dev():
 
 
 def close(actual, desired, rtol, what=""):
-    actual = actual.detach().cpu().numpy() if torch.is_tensor(actual) else actual
-    scale = float(np.abs(desired).max()) if desired.size else 0.0
-    np.testing.assert_allclose(actual, desired, rtol=rtol, atol=rtol * max(scale, 1e-30),
-                               err_msg=what)
+    """conftest.parity_close: norm-relative and elementwise-relative asserts, worst errors recorded."""
+    parity_close(actual, desired, rtol, what)
 
 
 def run_hip(dev, inp, w, oy, ox, gout, d, radius=-1, deterministic=False, need=(True,) * 4):
@@ -345,3 +343,69 @@ def test_full_size_grad_input_conserves_mass(dev, full):
         inp.grad = None
         artemis_amd.synth(inp, w, oy, ox, 1).backward(gout)
         assert torch.equal(g1, inp.grad)
+
+
+def test_nonfinite_frame_texels_poison_only_the_pixels_that_read_them(dev, oracle):
+    """Inf / NaN texels in the FRAME (not the offsets) with many out-of-tile taps: a far tap is
+    dropped from the LDS pass by a select, so an unrelated non-finite texel under its clamped LDS
+    address must not leak into pixels the oracle leaves finite (0 * Inf = NaN otherwise)."""
+    inp, w, oy, ox, gout = make_operands(1, 3, 40, 200, regime="gauss4", seed=41)
+    rng = np.random.default_rng(41)
+    for _ in range(8):
+        y, x = int(rng.integers(0, 44)), int(rng.integers(0, 204))
+        inp[0, int(rng.integers(0, 3)), y, x] = [np.inf, -np.inf, np.nan][int(rng.integers(0, 3))]
+    # the last texels of the frame / of the first tiles: where clamped LDS addresses point
+    inp[0, 0, 43, 203] = np.inf
+    inp[0, 1, 31, 131] = np.nan
+    ref = oracle.forward(inp, w, oy, ox, 1)
+    _, rgw, rga, rgb = oracle.backward(gout, inp, w, oy, ox, 1, with_input=False)
+    assert np.isfinite(ref).mean() > 0.5
+    for radius in (-1, 2, 4, 0):
+        out, (gi, gw, ga, gb) = run_hip(dev, inp, w, oy, ox, gout, 1, radius,
+                                        need=(False, True, True, True))
+        assert np.array_equal(np.isfinite(out), np.isfinite(ref)), f"radius {radius}"
+        ok = np.isfinite(ref)
+        close(out[ok], ref[ok], FWD_RTOL, "output")
+        for g, r, name in ((gw, rgw, "grad_weight"), (ga, rga, "grad_offset_y"),
+                           (gb, rgb, "grad_offset_x")):
+            assert np.array_equal(np.isfinite(g), np.isfinite(r)), f"{name}, radius {radius}"
+            ok = np.isfinite(r)
+            close(g[ok], r[ok], BWD_RTOL, name)
+
+
+def test_tiny_gradients_do_not_overflow_the_fixed_point_scale(dev, oracle):
+    """gradOutput ~ 1e-25 and weights ~ 1e-8: the fixed-point scale of gradInput would need 2^S
+    beyond fp32's range; it is clamped, and the (tiny) result still follows the fp64 adjoint."""
+    inp, w, oy, ox, gout = make_operands(1, 3, 24, 100, regime="gauss1", seed=42)
+    w = (w * 1e-8).astype(np.float32)
+    gout = (gout * 1e-25).astype(np.float32)
+    ref = oracle.grad_input(gout, inp.shape, w, oy, ox, 1)
+    assert 0 < np.abs(ref).max() < 1e-30
+    for radius, det in ((-1, False), (-1, True), (0, True), (0, False)):
+        gi = run_hip(dev, inp, w, oy, ox, gout, 1, radius, deterministic=det,
+                     need=(True, False, False, False))[1][0]
+        close(gi, ref, BWD_RTOL, "grad_input")
+
+
+def test_options_in_force_at_forward_govern_the_backward(dev, oracle):
+    """deterministic=True around the forward only: autograd runs backward later, outside the
+    `with`, and must still use the deterministic gradInput path (bit-equal run to run and equal to
+    a run with the option set throughout)."""
+    import artemis_amd
+    inp, w, oy, ox, gout = make_operands(2, 3, 37, 90, regime="gauss4", seed=43)
+
+    def run(scope):
+        t = [torch.from_numpy(a).to(dev).requires_grad_(i == 0) for i, a in enumerate((inp, w, oy, ox))]
+        with artemis_amd.synth_options(deterministic=True, tile_radius=4):
+            out = artemis_amd.FunctionSynth.apply(*t, 1)
+            if scope == "inside":
+                out.backward(torch.from_numpy(gout).to(dev))
+        if scope == "outside":
+            assert artemis_amd.options.deterministic is False
+            out.backward(torch.from_numpy(gout).to(dev))
+        torch.cuda.synchronize()
+        return t[0].grad.cpu().numpy()
+
+    a, b, c = run("outside"), run("outside"), run("inside")
+    assert np.array_equal(a, b) and np.array_equal(a, c)
+    close(a, oracle.grad_input(gout, inp.shape, w, oy, ox, 1), BWD_RTOL, "grad_input")

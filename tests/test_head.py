@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import make_operands
+from conftest import make_operands, parity_close
 
 FWD_RTOL = 1e-5
 BWD_RTOL = 1e-4
@@ -28,9 +28,8 @@ def head_operands(B, T, H, W, regime="gauss1", seed=0, weights="softmax"):
 
 
 def close(actual, desired, rtol, what="", floor=1e-30):
-    actual = actual.detach().cpu().numpy() if torch.is_tensor(actual) else actual
-    scale = float(np.abs(desired).max()) if desired.size else 0.0
-    np.testing.assert_allclose(actual, desired, rtol=rtol, atol=rtol * max(scale, floor), err_msg=what)
+    """conftest.parity_close: norm-relative and elementwise-relative asserts, worst errors recorded."""
+    parity_close(actual, desired, rtol, what, floor)
 
 
 # ---------------------------------------------------------------- oracle (CPU)

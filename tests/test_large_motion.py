@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import make_operands
+from conftest import make_operands, parity_close
 from test_head import head_operands
 
 pytestmark = pytest.mark.gpu
@@ -23,9 +23,8 @@ def dev():
 
 
 def close(actual, desired, rtol, what="", floor=1e-30):
-    actual = actual.detach().cpu().numpy() if torch.is_tensor(actual) else actual
-    scale = float(np.abs(desired).max()) if desired.size else 0.0
-    np.testing.assert_allclose(actual, desired, rtol=rtol, atol=rtol * max(scale, floor), err_msg=what)
+    """conftest.parity_close: norm-relative and elementwise-relative asserts, worst errors recorded."""
+    parity_close(actual, desired, rtol, what, floor)
 
 
 def moving_offsets(shape, kind, rng):
