@@ -31,6 +31,7 @@ SIGNATURES = {
     "artemis_synth_forward_ex": (_i, [_vp] * 5 + [_i] * 12 + [_vp]),
     "artemis_synth_backward_ex": (_i, [_vp] * 9 + [_i] * 13 + [_vp, ctypes.c_size_t, _vp]),
     "artemis_synth_backward_workspace_bytes_ex": (ctypes.c_size_t, [_i] * 9),
+    "artemis_synth_backward_noalloc": (_i, [_vp] * 9 + [_i] * 13 + [_vp]),
     "artemis_synth_head_forward": (_i, [_vp, _i] + [_vp] * 5 + [_i] * 9 + [_vp]),
     "artemis_synth_head_backward": (_i, [_vp, _i] + [_vp] * 9 + [_i] * 9 + [_vp]),
     "artemis_synth_offset_radius": (_i, [_vp, _vp, ctypes.c_size_t, _vp, _vp]),

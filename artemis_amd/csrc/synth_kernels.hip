@@ -422,6 +422,73 @@ int artemis_synth_backward_ex(const void *input, const float *weight, const floa
                         workspace, workspace_bytes, stream);
 }
 
+// ---- allocation-free backward ----------------------------------------------------------------
+// The workspace of artemis_synth_backward_ex (fixed-point header + int64 image of gradInput) held
+// inside the library.  `scratch` is a HOST-side stand-in for the device array: host code never
+// passes it anywhere; it resolves each device's own copy once (hipGetSymbolAddress with that device
+// current) and uses that pointer.
+// (`used`: no kernel names it -- the kernels take the resolved pointer as an argument -- so it must be
+// kept in the code object explicitly)
+static __device__ __align__(256) __attribute__((used)) unsigned char
+    scratch[ARTEMIS_SYNTH_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::atomic<void *> g_scratch_ptr[kMaxDevices];  // per device; racing first calls store one value
+
+int scratch_for_current_device(void **out)
+{
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail((int)e, "hipGetDevice: %s", hipGetErrorString(e));
+    if (dev < 0 || dev >= kMaxDevices)
+        return fail(hipErrorInvalidValue, "artemis_synth_backward_noalloc: device %d not supported "
+                    "(0..%d)", dev, kMaxDevices - 1);
+    void *p = g_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (!p) {
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p)
+            return fail(e != hipSuccess ? (int)e : (int)hipErrorInvalidSymbol,
+                        "hipGetSymbolAddress(scratch) on device %d: %s", dev, hipGetErrorString(e));
+        g_scratch_ptr[dev].store(p, std::memory_order_release);
+    }
+    *out = p;
+    return 0;
+}
+}  // namespace
+
+int artemis_synth_backward_noalloc(const void *input, const float *weight, const float *offset_y,
+                                   const float *offset_x, const float *grad_output,
+                                   float *grad_input, float *grad_weight, float *grad_offset_y,
+                                   float *grad_offset_x, int N, int C, int H, int W, int k, int d,
+                                   int in_H, int in_W, int org_y, int org_x, int frame_dtype,
+                                   int gin_mode, int tile_radius, void *stream)
+{
+    Geom g;
+    const int rc = make_geom_ex(g, N, C, H, W, k, d, in_H, in_W, org_y, org_x);
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+    if (rc == 0 && grad_input &&
+        (gin_mode == ARTEMIS_SYNTH_GIN_ATOMIC || gin_mode == ARTEMIS_SYNTH_GIN_DETERMINISTIC)) {
+        // the bound that holds for every tile_radius, as the size query reports it
+        const size_t need = ws_bytes_needed(g, gin_mode, tiled_ok(g) ? 1 : 0);
+        if (need > (size_t)ARTEMIS_SYNTH_NOALLOC_SCRATCH_BYTES)
+            return fail(hipErrorInvalidValue,
+                        "artemis_synth_backward_noalloc: grad_input of %lld elements in this gin_mode "
+                        "needs %zu scratch bytes, the built-in scratch holds %zu "
+                        "(ARTEMIS_SYNTH_NOALLOC_SCRATCH_BYTES); use artemis_synth_backward_ex with a "
+                        "caller workspace", (long long)N * C * in_H * in_W, need,
+                        (size_t)ARTEMIS_SYNTH_NOALLOC_SCRATCH_BYTES);
+        if (need) {
+            if (const int e = scratch_for_current_device(&ws)) return e;
+            ws_bytes = (size_t)ARTEMIS_SYNTH_NOALLOC_SCRATCH_BYTES;
+        }
+    }
+    return run_backward(g, rc, input, weight, offset_y, offset_x, grad_output, grad_input,
+                        grad_weight, grad_offset_y, grad_offset_x, gin_mode, tile_radius, frame_dtype,
+                        ws, ws_bytes, stream);
+}
+
 // ---- fused ChronoSynth head ----------------------------------------------------------------
 static int head_setup(Geom &g, HeadArgs &ha, const char *what, const void *const *frames, int T,
                       const float *occlusion, int B, int H, int W, int in_H, int in_W, int org_y,

@@ -134,6 +134,34 @@ int artemis_synth_backward_ex(const void *input, const float *weight, const floa
 size_t artemis_synth_backward_workspace_bytes_ex(int N, int C, int H, int W, int k, int d, int in_H,
                                                  int in_W, int gin_mode);
 
+/* ---- allocation-free backward --------------------------------------------------------------
+ * NO COUNTERPART IN THE REFERENCE.  For callers that cannot allocate device memory around the
+ * call: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
+ * artemis_synth_backward_ex with its caller-provided `workspace` replaced by a device array that
+ * lives inside the library (a file-scope `static __device__` array of
+ * ARTEMIS_SYNTH_NOALLOC_SCRATCH_BYTES bytes, held by every GPU the library runs on until the
+ * process ends); every other argument, every kernel and every result bit are those of
+ * artemis_synth_backward_ex.  The call itself allocates and frees nothing (no hipMalloc /
+ * hipFree / allocating library routine); the caller still passes all inputs and outputs.
+ *  - limit: the workspace this problem needs (artemis_synth_backward_workspace_bytes_ex: 256 B
+ *    in atomic mode, 256 + 8 B per grad_input element in deterministic mode, 0 without
+ *    grad_input) must not exceed ARTEMIS_SYNTH_NOALLOC_SCRATCH_BYTES -- i.e. a deterministic
+ *    grad_input of up to 8,388,576 elements (one padded 1080p RGB frame is 6,256,848); larger
+ *    problems are refused with hipErrorInvalidValue and a message, before any GPU work.
+ *  - all calls on one GPU share that GPU's array and it keeps the previous call's contents; each
+ *    call clears what it needs (hipMemsetAsync on `stream`), so consecutive calls on ONE stream
+ *    are safe, while calls that overlap on one GPU (different streams or threads) and both
+ *    request grad_input RACE on it -- serialise them.  Calls without grad_input never touch it.
+ *  - the array's device address is resolved once per device, on the first call made with that
+ *    device current (hipGetSymbolAddress); make that first call outside graph capture. */
+#define ARTEMIS_SYNTH_NOALLOC_SCRATCH_BYTES (64u << 20)
+int artemis_synth_backward_noalloc(const void *input, const float *weight, const float *offset_y,
+                                   const float *offset_x, const float *grad_output,
+                                   float *grad_input, float *grad_weight, float *grad_offset_y,
+                                   float *grad_offset_x, int N, int C, int H, int W, int k, int d,
+                                   int in_H, int in_W, int org_y, int org_x, int frame_dtype,
+                                   int gin_mode, int tile_radius, void *stream);
+
 /* ---- fused ChronoSynth head --------------------------------------------------------------
  * One call for what the reference's only caller does around the op for one pyramid level,
  * model/chrono_synth.py:114-129:
