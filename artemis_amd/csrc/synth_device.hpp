@@ -630,6 +630,182 @@ __device__ __forceinline__ Centre tile_centre(const float *__restrict__ ab,
     return c;
 }
 
+// ------------------------------------------------------------------------------------------
+// Several windows per tile.  One window follows ONE motion; a tile that straddles a motion
+// boundary (object in front of a background) or sits on a steep flow gradient has a second
+// population of taps that no single centre serves, and sending all of those through the global
+// fix-up is TA-bound (a 1080p frame of smooth +-30 px flow ran at 1/5 of the headline rate).
+// So after a pass over the taps the workgroup votes: when enough of its pixels still have taps
+// outside every window staged so far, and one of them shows a coherent displacement, the tile is
+// re-staged around that displacement and the waves that own such pixels run the (pipelined) tap
+// loop again, adding / storing only the taps that the new window serves and no earlier one did.
+// Up to kMaxPasses windows; whatever is left after that takes the global fix-up.  Everything is
+// a pure function of the operands (the vote picks the wave with the most such pixels, lowest
+// index on ties), so results do not vary run to run.
+// ------------------------------------------------------------------------------------------
+#ifndef SYNTH_MAX_PASSES
+#define SYNTH_MAX_PASSES 3
+#endif
+#ifndef SYNTH_PASS_MIN_PIXELS
+#define SYNTH_PASS_MIN_PIXELS 24
+#endif
+constexpr int kMaxPasses = SYNTH_MAX_PASSES;
+constexpr int kPassMinPixels = SYNTH_PASS_MIN_PIXELS;  // pixels with unserved taps that justify a pass
+constexpr float kNoCentre = 1.0e30f;                   // a window that serves nothing
+
+struct Windows {
+    Centre c0, c1, c2;  // unused ones at kNoCentre
+};
+
+__device__ __forceinline__ Windows one_window(Centre c)
+{
+    return Windows{c, Centre{kNoCentre, kNoCentre}, Centre{kNoCentre, kNoCentre}};
+}
+
+// smallest reach of a tap over all windows: served from LDS by some pass iff <= R
+__device__ __forceinline__ float windows_reach(float a, float b, const Windows &w)
+{
+    return fminf(tap_reach(a, b, w.c0), fminf(tap_reach(a, b, w.c1), tap_reach(a, b, w.c2)));
+}
+
+template <int R>
+__device__ __forceinline__ bool tap_in_windows(float a, float b, const Windows &w)
+{
+    return windows_reach(a, b, w) <= (float)R;
+}
+
+// The unserved taps of pixel (y, xs), lane l < 25 looking at tap l: truncated displacement and
+// whether no window serves the tap yet.
+template <int R>
+__device__ __forceinline__ bool unserved_tap(const float *__restrict__ ab,
+                                             const float *__restrict__ bb, size_t plane,
+                                             const Geom &g, int y, int xs, const Windows &w,
+                                             float &ia, float &ib)
+{
+    const int l = threadIdx.x & 63;
+    ia = ib = 0.f;
+    if (l >= 25) return false;
+    const size_t o = (size_t)l * plane + (size_t)y * g.W + xs;
+    const float a = ab[o], b = bb[o];
+    ia = (float)(int)a;
+    ib = (float)(int)b;
+    return !(windows_reach(a, b, w) <= (float)R);
+}
+
+// Centre for another window, taken from pixel (y, xs): of its unserved taps the first one seeds a
+// cluster -- the unserved taps displaced within R of it -- and the centre is the cluster's rounded
+// mean displacement.  (A plain mean over all unserved taps fails on a pixel whose taps point at
+// two objects.)  ok = false when the pixel has no unserved tap or its displacement is absurd.
+// Wave-uniform result.
+template <int R>
+__device__ __forceinline__ Centre unserved_centre(const float *__restrict__ ab,
+                                                  const float *__restrict__ bb, size_t plane,
+                                                  const Geom &g, int y, int xs, const Windows &w,
+                                                  bool &ok)
+{
+    float ia, ib;
+    const bool far = unserved_tap<R>(ab, bb, plane, g, y, xs, w, ia, ib);
+    const unsigned long long fmask = __ballot(far);
+    const int seed = fmask ? __ffsll((long long)fmask) - 1 : 0;
+    const float sy = __shfl(ia, seed), sx = __shfl(ib, seed);
+    const bool member = far && fabsf(ia - sy) <= (float)R && fabsf(ib - sx) <= (float)R;
+    const float n = (float)__popcll(__ballot(member));
+    const float my = rintf(wave_sum(member ? ia : 0.f) / fmaxf(n, 1.f));
+    const float mx = rintf(wave_sum(member ? ib : 0.f) / fmaxf(n, 1.f));
+    ok = n > 0.f && fabsf(my) < 1.0e6f && fabsf(mx) < 1.0e6f;
+    Centre c;
+    c.y = __builtin_amdgcn_readfirstlane(my);
+    c.x = __builtin_amdgcn_readfirstlane(mx);
+    return c;
+}
+
+// The vote after a pass: all waves agree on whether to stage another window and where.
+//  1. Every wave reports how many of its pixels still have unserved taps; below kPassMinPixels
+//     for the whole tile nothing more happens (the fix-up handles a few pixels faster than a pass).
+//  2. Otherwise every wave with such pixels proposes a centre from its first one and votes for it
+//     only if it would pay: the candidate must serve at least 3/4 of the unserved taps of three
+//     other such pixels of the wave (first / last flagged row, first / last lane).  A window is
+//     staged when the waves in favour own at least half of the tile's pixels in question, at the
+//     centre of the wave that owns most.  Independent large offsets (sigma = 4 px at R = 8: most
+//     pixels have a far tap or two, each in its own direction) fail that test in every wave, so
+//     they keep going straight to the fix-up and their bits do not depend on the tiling.
+// flagged[j]: ballot of row j's pixels with unserved taps (owners only).  Contains one or two
+// barriers: every wave of the workgroup calls it, active or not.  slot: WAVES x 4 floats of LDS.
+template <int R, int WAVES, int ROWS>
+__device__ __forceinline__ bool vote_next_window(float *slot, int wv, bool active,
+                                                 const unsigned long long (&flagged)[ROWS],
+                                                 const int (&rowy)[ROWS], int wx0,
+                                                 const float *__restrict__ ab,
+                                                 const float *__restrict__ bb, size_t plane,
+                                                 const Geom &g, const Windows &w, Centre &next)
+{
+    int cnt = 0, fy = 0, ly = 0;
+    unsigned long long fb = 0, lb = 0;
+    if (active) {
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {
+            cnt += __popcll(flagged[j]);
+            if (flagged[j]) {
+                if (!fb) {
+                    fb = flagged[j];
+                    fy = rowy[j];
+                }
+                lb = flagged[j];
+                ly = rowy[j];
+            }
+        }
+    }
+    const bool lane0 = (threadIdx.x & 63) == 0;
+    if (lane0) slot[wv * 4 + 0] = (float)cnt;
+    __syncthreads();
+    float total = 0.f;
+#pragma unroll
+    for (int i = 0; i < WAVES; ++i) total += slot[i * 4 + 0];
+    next = Centre{0.f, 0.f};
+    if (__builtin_amdgcn_readfirstlane((int)(total < (float)kPassMinPixels))) return false;
+
+    Centre cand = {0.f, 0.f};
+    bool yes = false;
+    if (cnt) {  // wave-uniform
+        cand = unserved_centre<R>(ab, bb, plane, g, fy, wx0 + __ffsll((long long)fb) - 1, w, yes);
+        if (yes) {
+            const int sx[3] = {wx0 + 63 - __clzll((long long)fb), wx0 + __ffsll((long long)lb) - 1,
+                               wx0 + 63 - __clzll((long long)lb)};
+            const int sy[3] = {fy, ly, ly};
+            int all = 0, served = 0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                float ia, ib;
+                const bool far = unserved_tap<R>(ab, bb, plane, g, sy[i], sx[i], w, ia, ib);
+                all += __popcll(__ballot(far));
+                served += __popcll(__ballot(
+                    far && fabsf(ia - cand.y) <= (float)R && fabsf(ib - cand.x) <= (float)R));
+            }
+            yes = 4 * served >= 3 * all;
+        }
+    }
+    if (lane0) {
+        slot[wv * 4 + 1] = yes ? (float)cnt : 0.f;
+        slot[wv * 4 + 2] = cand.y;
+        slot[wv * 4 + 3] = cand.x;
+    }
+    __syncthreads();
+    float in_favour = 0.f, best = 0.f;
+#pragma unroll
+    for (int i = 0; i < WAVES; ++i) {
+        const float c = slot[i * 4 + 1];
+        in_favour += c;
+        if (c > best) {
+            best = c;
+            next.y = slot[i * 4 + 2];
+            next.x = slot[i * 4 + 3];
+        }
+    }
+    next.y = __builtin_amdgcn_readfirstlane(next.y);
+    next.x = __builtin_amdgcn_readfirstlane(next.x);
+    return __builtin_amdgcn_readfirstlane((int)(best > 0.f && 2.f * in_favour >= total)) != 0;
+}
+
 // Contribution of ONE tap (clamped global gathers), channels 0..2.
 template <class FP>
 __device__ __forceinline__ Float3 fwd_tap_global(FP ip, const Geom &g, float wv,
@@ -653,7 +829,7 @@ template <int R, class FP>
 __device__ __forceinline__ Float3 fwd_outside_coop(FP ip,
                                                    const float *__restrict__ wb,
                                                    const float *__restrict__ ab,
-                                                   const float *__restrict__ bb, const Geom &g, Centre ctr, int y,
+                                                   const float *__restrict__ bb, const Geom &g, const Windows &win, int y,
                                                    int xs)
 {
     const int l = threadIdx.x & 63;
@@ -662,7 +838,7 @@ __device__ __forceinline__ Float3 fwd_outside_coop(FP ip,
     if (l < 25) {
         const size_t o = (size_t)l * plane + (size_t)y * g.W + xs;
         const float a = ab[o], b = bb[o];
-        if (!tap_in_tile<R>(a, b, ctr)) {
+        if (!tap_in_windows<R>(a, b, win)) {
             const int r = l / 5, s = l - 5 * r;
             c = fwd_tap_global(ip, g, wb[o], a, b, y + g.oy0 + r, xs + g.ox0 + s);
         }
@@ -678,7 +854,7 @@ template <int R, class FP>
 __device__ __forceinline__ Float3 fwd_outside_lane(FP ip,
                                                    const float *__restrict__ wp,
                                                    const float *__restrict__ ap,
-                                                   const float *__restrict__ bp, const Geom &g, Centre ctr, int y,
+                                                   const float *__restrict__ bp, const Geom &g, const Windows &win, int y,
                                                    int x)
 {
     const size_t plane = (size_t)g.H * g.W;
@@ -689,7 +865,7 @@ __device__ __forceinline__ Float3 fwd_outside_lane(FP ip,
         for (int s = 0; s < 5; ++s) {
             const size_t o = (size_t)(r * 5 + s) * plane;
             const float a = ap[o], b = bp[o];
-            if (!tap_in_tile<R>(a, b, ctr)) {
+            if (!tap_in_windows<R>(a, b, win)) {
                 const Float3 t = fwd_tap_global(ip, g, wp[o], a, b, y + g.oy0 + r, x + g.ox0 + s);
                 c.x += t.x;
                 c.y += t.y;
@@ -739,7 +915,7 @@ __device__ __forceinline__ float bwd_outside_coop(FP ip,
                                                   const float *__restrict__ bb,
                                                   const float *__restrict__ gn, float *__restrict__ gwn,
                                                   float *__restrict__ goyn, float *__restrict__ goxn,
-                                                  const Geom &g, Centre ctr, int y, int xs, float scale,
+                                                  const Geom &g, const Windows &win, int y, int xs, float scale,
                                                   bool want_sum)
 {
     const int l = threadIdx.x & 63;
@@ -749,7 +925,7 @@ __device__ __forceinline__ float bwd_outside_coop(FP ip,
         const size_t pix = (size_t)y * g.W + xs;
         const size_t o = (size_t)l * plane + pix;
         const float a = ab[o], b = bb[o];
-        if (!tap_in_tile<R>(a, b, ctr)) {
+        if (!tap_in_windows<R>(a, b, win)) {
             const int r = l / 5, s = l - 5 * r;
             c = bwd_tap_global(ip, g, wb[o], a, b, gn[pix], gn[plane + pix], gn[2 * plane + pix],
                                y + g.oy0 + r, xs + g.ox0 + s, gwn, goyn, goxn, o, scale);
@@ -765,7 +941,7 @@ __device__ __forceinline__ float bwd_outside_lane(FP ip,
                                                   const float *__restrict__ bb, float d0, float d1,
                                                   float d2, float *__restrict__ gwn,
                                                   float *__restrict__ goyn, float *__restrict__ goxn,
-                                                  const Geom &g, Centre ctr, int y, int x, float scale)
+                                                  const Geom &g, const Windows &win, int y, int x, float scale)
 {
     const size_t plane = (size_t)g.H * g.W;
     const size_t pix = (size_t)y * g.W + x;
@@ -776,7 +952,7 @@ __device__ __forceinline__ float bwd_outside_lane(FP ip,
         for (int s = 0; s < 5; ++s) {
             const size_t o = (size_t)(r * 5 + s) * plane + pix;
             const float a = ab[o], b = bb[o];
-            if (!tap_in_tile<R>(a, b, ctr))
+            if (!tap_in_windows<R>(a, b, win))
                 c += bwd_tap_global(ip, g, wb[o], a, b, d0, d1, d2, y + g.oy0 + r, x + g.ox0 + s, gwn,
                                     goyn, goxn, o, scale);
         }
@@ -923,6 +1099,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
     constexpr int TW = 64 * WX, WY = WAVES / WX, TH = WY * ROWS;
     constexpr int LW = TileShape<R, TH, TW>::LW, LH = TileShape<R, TH, TW>::LH;
     __shared__ f32x4 tile[LH * LW];
+    __shared__ float vote_slot[WAVES * 4];
     const lds_f32x4 *ltile = (const lds_f32x4 *)tile;
     int tx0, ty0;
     if (!tile_origin<TH, TW>(g, tx0, ty0)) return;
@@ -935,7 +1112,9 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
     // same stores as that column's owner), like the rows below: no lane ever retires on its own,
     // so wave-wide operations in the fix-up see all 64 lanes.
     const int x = min(wx0 + (int)threadIdx.x, g.W - 1), px = x - tx0;
-    const bool active = ty0 + wy < g.H && wx0 < g.W;  // wave-uniform
+    const bool owner = wx0 + (int)threadIdx.x == x;   // not a right-edge duplicate
+    // wave-uniform; a wave without pixels only takes part in the tile fills, barriers and votes
+    const bool active = ty0 + wy < g.H && wx0 < g.W;
 
     // A row past the bottom edge is replaced by the last image row: the wave then recomputes
     // and re-stores exactly what that row's owner stores (same operands, same arithmetic), which
@@ -980,71 +1159,123 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
             }
         }
 
-        const Centre ctr = tile_centre<R>(ab, bb, pl, g, tx0, ty0, TH, TW);
-        const int cyi = (int)ctr.y, cxi = (int)ctr.x;
-        if (HEAD && f > 0) __syncthreads();  // every wave is done with the previous frame's tile
-        fill_tile_n<R, TH, 64 * WAVES, TW>(tile, ip, g, ty0 + g.oy0 - R + cyi, tx0 + g.ox0 - R + cxi, tid);
-        __syncthreads();
-        if (!active) {
-            if constexpr (HEAD) continue;  // keeps taking part in the fills and barriers
-            else return;
-        }
-        const int cbase = (cyi * LW + cxi) * 16;  // the tile's shift, folded into the row bases
-
         float acc0[ROWS], acc1[ROWS], acc2[ROWS];
-        float mabs[ROWS];
+        float mabs[ROWS];  // per row: the largest (over taps) of the smallest (over windows) reach
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) {
             acc0[j] = acc1[j] = acc2[j] = 0.f;
             mabs[j] = 0.f;
         }
-        static_for<0, 25>([&](auto tc) {
-            constexpr int t = decltype(tc)::value;
-            constexpr int r = t / 5, s = t % 5;
-            TapCol<ROWS> nxt;
-            if (t < 24) load_tap_col<ROWS>(nxt, wb, ab, bb, pl, t + 1, rf, (unsigned)x);
-            __builtin_amdgcn_sched_barrier(0);
+
+        // One pass over the 25 taps with the window centred at `ctr`.  FIRST: the window is the
+        // tile's first one (every tap it serves is added); otherwise only taps that it serves and
+        // no earlier window (`prev`) did.
+        auto run_taps = [&](auto first_tag, const Centre ctr, const Windows &prev) {
+            constexpr bool FIRST = decltype(first_tag)::value != 0;
+            const int cbase = (((int)ctr.y) * LW + (int)ctr.x) * 16;  // the window's shift
 #pragma unroll
-            for (int j = 0; j < ROWS; ++j) {
-                const float wv = cur.w[j], a = cur.a[j], b = cur.b[j];
-                const int ia = (int)a, ib = (int)b;
-                const float fa = a - (float)ia, fb = b - (float)ib;
-                const float reach = fmaxf(fabsf((float)ia - ctr.y), fabsf((float)ib - ctr.x));
-                mabs[j] = fmaxf(mabs[j], reach);
-                const Corners q = tile_corners_at<R, TH, r * LW + s, TW>(ltile, ia, ib, rowbase[j] - cbase);
-                const float ga = 1.f - fa, gb = 1.f - fb;
-                const float c00 = ga * gb, c10 = fa * gb, c01 = ga * fb, c11 = fa * fb;
-                // A far tap is added by the fix-up instead.  Its term is dropped by a select, not by
-                // a zero weight: the clamped LDS address of a far tap points at an unrelated texel,
-                // and 0 * Inf / 0 * NaN from there would poison a pixel the reference leaves finite.
-                const bool near = reach <= (float)R;
-                const float n0 = acc0[j] + wv * (q.bl.x * c00 + q.tl.x * c10 + q.br.x * c01 + q.tr.x * c11);
-                const float n1 = acc1[j] + wv * (q.bl.y * c00 + q.tl.y * c10 + q.br.y * c01 + q.tr.y * c11);
-                const float n2 = acc2[j] + wv * (q.bl.z * c00 + q.tl.z * c10 + q.br.z * c01 + q.tr.z * c11);
-                acc0[j] = near ? n0 : acc0[j];
-                acc1[j] = near ? n1 : acc1[j];
-                acc2[j] = near ? n2 : acc2[j];
-                // Pin the arithmetic in place: instruction selection otherwise floats the
-                // chain-free FMAs to the end of the unrolled block, keeping every LDS result of
-                // the pixel live (512 VGPRs or spills).  The sched_barrier bounds the LDS results
-                // in flight to kRowGroup rows (16 VGPRs each).
-                asm volatile("" : "+v"(acc0[j]), "+v"(acc1[j]), "+v"(acc2[j]), "+v"(mabs[j]));
-                if (j % kRowGroup == kRowGroup - 1) __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < ROWS; ++j) mabs[j] = 0.f;
+            static_for<0, 25>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                constexpr int r = t / 5, s = t % 5;
+                TapCol<ROWS> nxt;
+                if (t < 24) load_tap_col<ROWS>(nxt, wb, ab, bb, pl, t + 1, rf, (unsigned)x);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < ROWS; ++j) {
+                    const float wv = cur.w[j], a = cur.a[j], b = cur.b[j];
+                    const int ia = (int)a, ib = (int)b;
+                    const float fa = a - (float)ia, fb = b - (float)ib;
+                    const float reach = fmaxf(fabsf((float)ia - ctr.y), fabsf((float)ib - ctr.x));
+                    bool near;
+                    if constexpr (FIRST) {
+                        mabs[j] = fmaxf(mabs[j], reach);
+                        near = reach <= (float)R;
+                    } else {
+                        const float before = windows_reach(a, b, prev);
+                        mabs[j] = fmaxf(mabs[j], fminf(reach, before));
+                        near = reach <= (float)R && !(before <= (float)R);
+                    }
+                    const Corners q = tile_corners_at<R, TH, r * LW + s, TW>(ltile, ia, ib, rowbase[j] - cbase);
+                    const float ga = 1.f - fa, gb = 1.f - fb;
+                    const float c00 = ga * gb, c10 = fa * gb, c01 = ga * fb, c11 = fa * fb;
+                    // A tap this window does not serve is added elsewhere.  Its term is dropped by a
+                    // select, not by a zero weight: the clamped LDS address of such a tap points at an
+                    // unrelated texel, and 0 * Inf / 0 * NaN from there would poison a pixel the
+                    // reference leaves finite.
+                    const float n0 = acc0[j] + wv * (q.bl.x * c00 + q.tl.x * c10 + q.br.x * c01 + q.tr.x * c11);
+                    const float n1 = acc1[j] + wv * (q.bl.y * c00 + q.tl.y * c10 + q.br.y * c01 + q.tr.y * c11);
+                    const float n2 = acc2[j] + wv * (q.bl.z * c00 + q.tl.z * c10 + q.br.z * c01 + q.tr.z * c11);
+                    acc0[j] = near ? n0 : acc0[j];
+                    acc1[j] = near ? n1 : acc1[j];
+                    acc2[j] = near ? n2 : acc2[j];
+                    // Pin the arithmetic in place: instruction selection otherwise floats the
+                    // chain-free FMAs to the end of the unrolled block, keeping every LDS result of
+                    // the pixel live (512 VGPRs or spills).  The sched_barrier bounds the LDS results
+                    // in flight to kRowGroup rows (16 VGPRs each).
+                    asm volatile("" : "+v"(acc0[j]), "+v"(acc1[j]), "+v"(acc2[j]), "+v"(mabs[j]));
+                    if (j % kRowGroup == kRowGroup - 1) __builtin_amdgcn_sched_barrier(0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                cur = nxt;
+            });
+        };
+
+        Windows win = one_window(tile_centre<R>(ab, bb, pl, g, tx0, ty0, TH, TW));
+        Centre ctr = win.c0;
+        unsigned long long flagged[ROWS];
+#pragma unroll 1
+        for (int p = 0;; ++p) {
+            // (the per-tap addresses are invariant in this loop too: keep them from being hoisted
+            // out of it and spilled, as in the head's frame loop)
+            pl = per_frame(pl);
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) rf[j] = per_frame(rf[j]);
+            // every wave is done with the previous window (frame f - 1's last one; within a frame
+            // the vote's barrier has already seen to that)
+            if (HEAD && f > 0 && p == 0) __syncthreads();
+            fill_tile_n<R, TH, 64 * WAVES, TW>(tile, ip, g, ty0 + g.oy0 - R + (int)ctr.y,
+                                               tx0 + g.ox0 - R + (int)ctr.x, tid);
+            __syncthreads();
+            if (p == 0) {
+                if (active) run_taps(IntTag<1>{}, ctr, win);
+            } else {
+                bool any = false;
+#pragma unroll
+                for (int j = 0; j < ROWS; ++j) any |= flagged[j] != 0;
+                if (active && any) {  // wave-uniform
+                    Windows prev = win;  // the windows before this one
+                    if (p == 1) prev.c1 = Centre{kNoCentre, kNoCentre};
+                    else prev.c2 = Centre{kNoCentre, kNoCentre};
+                    load_tap_col<ROWS>(cur, wb, ab, bb, pl, 0, rf, (unsigned)x);
+                    run_taps(IntTag<0>{}, ctr, prev);
+                }
             }
-            __builtin_amdgcn_sched_barrier(0);
-            cur = nxt;
-        });
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
+                flagged[j] = active ? __ballot(!(mabs[j] <= (float)R) && owner) : 0ull;
+            if (p + 1 == kMaxPasses) break;
+            Centre next;
+            if (!vote_next_window<R, WAVES, ROWS>(vote_slot, wv, active, flagged, rowy, wx0, ab, bb, pl, g,
+                                                  win, next))
+                break;
+            if (p == 0) win.c1 = next;
+            else win.c2 = next;
+            ctr = next;
+        }
+        if (!active) continue;  // (it has taken part in this frame's fills, barriers and votes)
+
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) {
-            // taps that left the tile are added through clamped global gathers
+            // taps that no window served are added through clamped global gathers
+            unsigned long long todo = flagged[j];
             const bool flag = !(mabs[j] <= (float)R);
-            unsigned long long todo = __ballot(flag && wx0 + (int)threadIdx.x == x);
             if (todo) {  // wave-uniform, rare
                 if (__popcll(todo) <= kCoopMaxPixels) {
                     while (todo) {
                         const int b = __ffsll((long long)todo) - 1;
                         todo &= todo - 1;
-                        const Float3 c = fwd_outside_coop<R>(ip, wb, ab, bb, g, ctr, rowy[j], wx0 + b);
+                        const Float3 c = fwd_outside_coop<R>(ip, wb, ab, bb, g, win, rowy[j], wx0 + b);
                         if (x == wx0 + b) {  // the owner and its right-edge duplicates
                             acc0[j] += c.x;
                             acc1[j] += c.y;
@@ -1053,7 +1284,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
                     }
                 } else if (flag) {
                     const size_t o = rf[j] + x;
-                    const Float3 c = fwd_outside_lane<R>(ip, wb + o, ab + o, bb + o, g, ctr, rowy[j], x);
+                    const Float3 c = fwd_outside_lane<R>(ip, wb + o, ab + o, bb + o, g, win, rowy[j], x);
                     acc0[j] += c.x;
                     acc1[j] += c.y;
                     acc2[j] += c.z;
@@ -1072,7 +1303,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
             }
         }
     }
-    if (HEAD && !active) return;
+    if (!active) return;
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) {
         float *orow = out + (size_t)n * 3 * plane + roff[j];
@@ -1096,6 +1327,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
     constexpr int TW = 64 * WX, WY = WAVES / WX, TH = WY * ROWS;
     constexpr int LW = TileShape<R, TH, TW>::LW, LH = TileShape<R, TH, TW>::LH;
     __shared__ f32x4 tile[LH * LW];
+    __shared__ float vote_slot[WAVES * 4];
     const lds_f32x4 *ltile = (const lds_f32x4 *)tile;
     int tx0, ty0;
     if (!tile_origin<TH, TW>(g, tx0, ty0)) return;
@@ -1106,7 +1338,8 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
     const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
     // lanes past the right edge duplicate the last image column (see forward)
     const int x = min(wx0 + (int)threadIdx.x, g.W - 1), px = x - tx0;
-    const bool active = ty0 + wy < g.H && wx0 < g.W;  // wave-uniform
+    const bool owner = wx0 + (int)threadIdx.x == x;
+    const bool active = ty0 + wy < g.H && wx0 < g.W;  // wave-uniform (see forward)
 
     int rowy[ROWS];  // rows past the bottom edge duplicate the last image row (see forward)
     size_t roff[ROWS];
@@ -1148,80 +1381,132 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
             }
         }
 
-        const Centre ctr = tile_centre<R>(ab, bb, pl, g, tx0, ty0, TH, TW);
-        const int cyi = (int)ctr.y, cxi = (int)ctr.x;
-        if (HEAD && f > 0) __syncthreads();  // every wave is done with the previous frame's tile
-        fill_tile_n<R, TH, 64 * WAVES, TW>(tile, ip, g, ty0 + g.oy0 - R + cyi, tx0 + g.ox0 - R + cxi, tid);
-        __syncthreads();
-        if (!active) {
-            if constexpr (HEAD) continue;
-            else return;
-        }
-        const int cbase = (cyi * LW + cxi) * 16;  // the tile's shift, folded into the row bases
-
         float mabs[ROWS];
-        if (f == 0) {  // gradOutput is the same for every frame of the head
-#pragma unroll
-            for (int j = 0; j < ROWS; ++j) {
-                d[j][0] = ld_stream(gb_ + rf[j] + (unsigned)x);
-                d[j][1] = ld_stream(gb_ + pl + rf[j] + (unsigned)x);
-                d[j][2] = ld_stream(gb_ + 2 * pl + rf[j] + (unsigned)x);
-            }
-        }
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) mabs[j] = 0.f;
-        static_for<0, 25>([&](auto tc) {
-            constexpr int t = decltype(tc)::value;
-            constexpr int r = t / 5, s = t % 5;
-            TapCol<ROWS> nxt;
-            if (t < 24) load_tap_col<ROWS>(nxt, wb, ab, bb, pl, t + 1, rf, (unsigned)x);
-            __builtin_amdgcn_sched_barrier(0);
+
+        // One pass over the 25 taps with the window centred at `ctr` (see forward).  FIRST: all
+        // three gradients of every tap are stored (those of a tap the window does not serve are
+        // overwritten later -- same lane or same wave, program order); otherwise only the taps
+        // that this window serves and no earlier one did are stored.
+        auto run_taps = [&](auto first_tag, const Centre ctr, const Windows &prev) {
+            constexpr bool FIRST = decltype(first_tag)::value != 0;
+            const int cbase = (((int)ctr.y) * LW + (int)ctr.x) * 16;  // the window's shift
 #pragma unroll
-            for (int j = 0; j < ROWS; ++j) {
-                const float wv = cur.w[j], a = cur.a[j], b = cur.b[j];
-                const int ia = (int)a, ib = (int)b;
-                const float fa = a - (float)ia, fb = b - (float)ib;
-                const float reach = fmaxf(fabsf((float)ia - ctr.y), fabsf((float)ib - ctr.x));
-                mabs[j] = fmaxf(mabs[j], reach);
-                const Corners q = tile_corners_at<R, TH, r * LW + s, TW>(ltile, ia, ib, rowbase[j] - cbase);
-                const float pbl = d[j][0] * q.bl.x + d[j][1] * q.bl.y + d[j][2] * q.bl.z;
-                const float ptl = d[j][0] * q.tl.x + d[j][1] * q.tl.y + d[j][2] * q.tl.z;
-                const float pbr = d[j][0] * q.br.x + d[j][1] * q.br.y + d[j][2] * q.br.z;
-                const float ptr_ = d[j][0] * q.tr.x + d[j][1] * q.tr.y + d[j][2] * q.tr.z;
-                const float dl = ptl - pbl, dr = ptr_ - pbr;
-                const float lft = pbl + fa * dl, rgt = pbr + fa * dr;
-                const float across = rgt - lft;
-                const size_t o = nb + (size_t)t * pl + rf[j];
-                if constexpr (HEAD) {
-                    const float gwr = lft + fb * across;
-                    const float gar = wv * (dl + fb * (dr - dl));
-                    const float gbr = wv * across;
-                    // a far tap's share comes from the fix-up, which also overwrites its stores
-                    // (a select of the product: 0 * NaN from a far tap's unrelated texel must not
-                    // enter the sum)
-                    const float ng = gocc[j] + wv * gwr;
-                    gocc[j] = reach <= (float)R ? ng : gocc[j];
-                    if (ALL || gw) st_stream(gw + o + (unsigned)x, occv[j] * gwr);
-                    if (ALL || goy) st_stream(goy + o + (unsigned)x, occv[j] * gar);
-                    if (ALL || gox) st_stream(gox + o + (unsigned)x, occv[j] * gbr);
-                    asm volatile("" : "+v"(mabs[j]), "+v"(gocc[j]));
-                } else {
-                    if (ALL || gw) st_stream(gw + o + (unsigned)x, lft + fb * across);
-                    if (ALL || goy) st_stream(goy + o + (unsigned)x, wv * (dl + fb * (dr - dl)));
-                    if (ALL || gox) st_stream(gox + o + (unsigned)x, wv * across);
+            for (int j = 0; j < ROWS; ++j) mabs[j] = 0.f;
+            static_for<0, 25>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                constexpr int r = t / 5, s = t % 5;
+                TapCol<ROWS> nxt;
+                if (t < 24) load_tap_col<ROWS>(nxt, wb, ab, bb, pl, t + 1, rf, (unsigned)x);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < ROWS; ++j) {
+                    const float wv = cur.w[j], a = cur.a[j], b = cur.b[j];
+                    const int ia = (int)a, ib = (int)b;
+                    const float fa = a - (float)ia, fb = b - (float)ib;
+                    const float reach = fmaxf(fabsf((float)ia - ctr.y), fabsf((float)ib - ctr.x));
+                    bool near;
+                    if constexpr (FIRST) {
+                        mabs[j] = fmaxf(mabs[j], reach);
+                        near = reach <= (float)R;
+                    } else {
+                        const float before = windows_reach(a, b, prev);
+                        mabs[j] = fmaxf(mabs[j], fminf(reach, before));
+                        near = reach <= (float)R && !(before <= (float)R);
+                    }
+                    const Corners q = tile_corners_at<R, TH, r * LW + s, TW>(ltile, ia, ib, rowbase[j] - cbase);
+                    const float pbl = d[j][0] * q.bl.x + d[j][1] * q.bl.y + d[j][2] * q.bl.z;
+                    const float ptl = d[j][0] * q.tl.x + d[j][1] * q.tl.y + d[j][2] * q.tl.z;
+                    const float pbr = d[j][0] * q.br.x + d[j][1] * q.br.y + d[j][2] * q.br.z;
+                    const float ptr_ = d[j][0] * q.tr.x + d[j][1] * q.tr.y + d[j][2] * q.tr.z;
+                    const float dl = ptl - pbl, dr = ptr_ - pbr;
+                    const float lft = pbl + fa * dl, rgt = pbr + fa * dr;
+                    const float across = rgt - lft;
+                    const size_t o = nb + (size_t)t * pl + rf[j];
+                    float gwr = lft + fb * across;
+                    float gar = wv * (dl + fb * (dr - dl));
+                    float gbr = wv * across;
+                    if constexpr (HEAD) {
+                        // a tap this window does not serve gets its share from the pass or fix-up
+                        // that computes it (a select of the sum: 0 * NaN from such a tap's
+                        // unrelated texel must not enter it)
+                        const float ng = gocc[j] + wv * gwr;
+                        gocc[j] = near ? ng : gocc[j];
+                        gwr = occv[j] * gwr;
+                        gar = occv[j] * gar;
+                        gbr = occv[j] * gbr;
+                        asm volatile("" : "+v"(gocc[j]));
+                    }
+                    if (FIRST || near) {
+                        if (ALL || gw) st_stream(gw + o + (unsigned)x, gwr);
+                        if (ALL || goy) st_stream(goy + o + (unsigned)x, gar);
+                        if (ALL || gox) st_stream(gox + o + (unsigned)x, gbr);
+                    }
                     asm volatile("" : "+v"(mabs[j]));
+                    if (j % kRowGroup == kRowGroup - 1) __builtin_amdgcn_sched_barrier(0);
                 }
-                if (j % kRowGroup == kRowGroup - 1) __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_sched_barrier(0);
+                cur = nxt;
+            });
+        };
+
+        Windows win = one_window(tile_centre<R>(ab, bb, pl, g, tx0, ty0, TH, TW));
+        Centre ctr = win.c0;
+        unsigned long long flagged[ROWS];
+#pragma unroll 1
+        for (int p = 0;; ++p) {
+            pl = per_frame(pl);  // (see forward)
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) rf[j] = per_frame(rf[j]);
+            if (HEAD && f > 0 && p == 0) __syncthreads();  // every wave is done with the previous window
+            fill_tile_n<R, TH, 64 * WAVES, TW>(tile, ip, g, ty0 + g.oy0 - R + (int)ctr.y,
+                                               tx0 + g.ox0 - R + (int)ctr.x, tid);
+            __syncthreads();
+            if (p == 0) {
+                if (active) {
+                    if (f == 0) {  // gradOutput is the same for every frame of the head
+#pragma unroll
+                        for (int j = 0; j < ROWS; ++j) {
+                            d[j][0] = ld_stream(gb_ + rf[j] + (unsigned)x);
+                            d[j][1] = ld_stream(gb_ + pl + rf[j] + (unsigned)x);
+                            d[j][2] = ld_stream(gb_ + 2 * pl + rf[j] + (unsigned)x);
+                        }
+                    }
+                    run_taps(IntTag<1>{}, ctr, win);
+                }
+            } else {
+                bool any = false;
+#pragma unroll
+                for (int j = 0; j < ROWS; ++j) any |= flagged[j] != 0;
+                if (active && any) {  // wave-uniform
+                    Windows prev = win;  // the windows before this one
+                    if (p == 1) prev.c1 = Centre{kNoCentre, kNoCentre};
+                    else prev.c2 = Centre{kNoCentre, kNoCentre};
+                    load_tap_col<ROWS>(cur, wb, ab, bb, pl, 0, rf, (unsigned)x);
+                    run_taps(IntTag<0>{}, ctr, prev);
+                }
             }
-            __builtin_amdgcn_sched_barrier(0);
-            cur = nxt;
-        });
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
+                flagged[j] = active ? __ballot(!(mabs[j] <= (float)R) && owner) : 0ull;
+            if (p + 1 == kMaxPasses) break;
+            Centre next;
+            if (!vote_next_window<R, WAVES, ROWS>(vote_slot, wv, active, flagged, rowy, wx0, ab, bb, pl, g,
+                                                  win, next))
+                break;
+            if (p == 0) win.c1 = next;
+            else win.c2 = next;
+            ctr = next;
+        }
+        if (!active) continue;  // (it has taken part in this frame's fills, barriers and votes)
+
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) {
-            // taps that left the tile: recomputed through clamped global gathers, overwriting
-            // what the hot loop stored for them (same lane or same wave: program order)
+            // taps that no window served: recomputed through clamped global gathers, overwriting
+            // what the first pass stored for them (same lane or same wave: program order)
+            unsigned long long todo = flagged[j];
             const bool flag = !(mabs[j] <= (float)R);
-            unsigned long long todo = __ballot(flag && wx0 + (int)threadIdx.x == x);
             if (todo) {  // wave-uniform, rare
                 float *gwn = gw ? gw + nb : nullptr, *goyn = goy ? goy + nb : nullptr,
                       *goxn = gox ? gox + nb : nullptr;
@@ -1231,12 +1516,12 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
                         todo &= todo - 1;
                         const float sc = HEAD ? __shfl(occv[j], b) : 1.f;
                         const float c = bwd_outside_coop<R>(ip, wb, ab, bb, gb_, gwn, goyn, goxn, g,
-                                                            ctr, rowy[j], wx0 + b, sc, HEAD);
+                                                            win, rowy[j], wx0 + b, sc, HEAD);
                         if (HEAD && x == wx0 + b) gocc[j] += c;
                     }
                 } else if (flag) {
                     const float c = bwd_outside_lane<R>(ip, wb, ab, bb, d[j][0], d[j][1], d[j][2], gwn,
-                                                        goyn, goxn, g, ctr, rowy[j],
+                                                        goyn, goxn, g, win, rowy[j],
                                                         HEAD ? in_branch(x) : x,
                                                         HEAD ? occv[j] : 1.f);
                     if (HEAD) gocc[j] += c;

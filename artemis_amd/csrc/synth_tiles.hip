@@ -200,6 +200,7 @@ typedef float frame_t;
 template void launch_fwd_tiled<SYNTH_TILE_R, frame_t>(const frame_t *, const float *, const float *,
                                                       const float *, float *, const Geom &,
                                                       hipStream_t);
+#ifndef SYNTH_DEV_ONLY_FWD  // (developer builds: compile just the forward to look at its registers)
 template void launch_bwd_tiled<SYNTH_TILE_R, frame_t>(const frame_t *, const float *, const float *,
                                                       const float *, const float *, float *, float *,
                                                       float *, const Geom &, hipStream_t);
@@ -217,5 +218,6 @@ template void launch_gin_tiled<SYNTH_TILE_R, true>(const float *, const float *,
                                                    const float *, float *, unsigned char *,
                                                    const Geom &, int, hipStream_t);
 #endif
+#endif  // SYNTH_DEV_ONLY_FWD
 
 }  // namespace asynth

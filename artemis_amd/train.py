@@ -1,15 +1,17 @@
-"""A Lightning-free training step around the synthesis head: ChronoSynth (this package's
-restatement, fused head op) + L1 loss + Adamax + MultiStepLR, one process per GPU with
-``torch.distributed`` -- the pieces of the reference's ``main.py`` that touch the hot path
+"""A Lightning-free training step: the whole ArTEMIS model (``--model artemis``, this package's
+restatement on stock ops + the fused head op) or one ChronoSynth head alone (``--model head``)
++ L1 loss + Adamax + MultiStepLR, one process per GPU with ``torch.distributed`` -- the pieces of
+the reference's ``main.py`` that touch the hot path
 (``main.py:45`` Adamax, ``:89-93`` MultiStepLR([40,60,75,85,95,100], gamma 0.5) stepped per epoch,
 ``loss.py:9`` L1; Lightning DDP ``:133``).
 
 The op itself needs no collective: the batch is sharded over ranks (``sharding.shard_batch``) and
-the only exchange of a step is DDP's gradient all-reduce of the module's parameters (RCCL over
-xGMI with backend ``nccl``; ``gloo`` works for rehearsals).  The encoder/decoder that produce the
-features upstream are stock PyTorch ops and are stood in for by given feature tensors.
+the only exchange of a step is DDP's gradient all-reduce of the module's parameters (29.09 M fp32 for
+the full model, RCCL over xGMI with backend ``nccl``; ``gloo`` works for rehearsals).  With
+``--model head`` the encoder/decoder are stood in for by given feature tensors.
 
-    torchrun --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m artemis_amd.train --steps 5
+    torchrun --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m artemis_amd.train \
+        --model artemis --batch 64 --size 256 --steps 5        # BASELINE configs[2]
 """
 from __future__ import annotations
 
@@ -20,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from .device import add_device_argument, select_device
-from .model import ChronoSynth
+from .model import ArTEMIS, ChronoSynth
 from .sharding import shard_bounds
 
 
@@ -35,6 +37,17 @@ def synthetic_batch(batch, num_features, size, seed, device):
     return (feats.to(device), [f.to(device) for f in frames], gt.to(device), t.to(device))
 
 
+def synthetic_frames(batch, size, seed, device):
+    """4 context frames (B, 3, H, W) in [0, 1], ground truth (B, 3, H, W), times (B,) drawn from the
+    septuplet's {0.25, 0.5, 0.75} (data/preprocessing/vimeo90k_septuplet_process.py)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    H, W = size
+    frames = [torch.rand(batch, 3, H, W, generator=g) for _ in range(4)]
+    gt = torch.rand(batch, 3, H, W, generator=g)
+    t = torch.tensor([0.25, 0.5, 0.75])[torch.randint(0, 3, (batch,), generator=g)]
+    return [f.to(device) for f in frames], gt.to(device), t.to(device)
+
+
 class HeadTrainer:
     """One ChronoSynth head under Adamax + MultiStepLR, data-parallel over the process group."""
 
@@ -46,16 +59,26 @@ class HeadTrainer:
                  seed=103, fused=True):
         torch.manual_seed(seed)          # config.py:62; same init on every rank
         self.device = device
-        self.module = ChronoSynth(4, num_features, 5, 1, apply_softmax=True, fused=fused).to(device)
+        self.module = self.build(num_features, fused).to(device)
         self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
         self.rank = torch.distributed.get_rank() if self.world > 1 else 0
         self.model = self.module
-        if self.world > 1:
+        # RCCL (backend "nccl"): DistributedDataParallel, bucketed all-reduce overlapped with the
+        # backward.  Any other backend is a rehearsal of the multi-rank control flow on fewer GPUs
+        # than ranks (gloo, ranks sharing a device): gradients are averaged by one all-reduce of
+        # the flattened gradient on the host instead -- DDP's bucketed CUDA all-reduce over gloo
+        # stalls for the full model when two ranks share one GPU.
+        self.ddp = self.world > 1 and torch.distributed.get_backend() == "nccl"
+        if self.ddp:
             self.model = nn.parallel.DistributedDataParallel(
                 self.module, device_ids=[device.index], broadcast_buffers=False)
         self.optimizer = torch.optim.Adamax(self.module.parameters(), lr=lr, betas=betas)
         self.scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, list(milestones), gamma=0.5)
         self.loss = nn.L1Loss(reduction="mean")
+
+    @staticmethod
+    def build(num_features, fused):
+        return ChronoSynth(4, num_features, 5, 1, apply_softmax=True, fused=fused)
 
     def shard(self, batch):
         """This rank's slice of a global batch (features, frames, gt, times).  The batch must
@@ -74,17 +97,60 @@ class HeadTrainer:
         out = self.model(feats, frames, tuple(gt.shape[-2:]), t)
         loss = self.loss(out, gt)
         loss.backward()                  # DDP all-reduces (averages) the parameter gradients here
+        self.average_gradients()
         self.optimizer.step()
         return loss.detach()
+
+    def average_gradients(self):
+        """The rehearsal path's gradient all-reduce (see __init__); a no-op under DDP."""
+        if self.world == 1 or self.ddp:
+            return
+        params = [p for p in self.module.parameters() if p.grad is not None]
+        flat = torch.cat([p.grad.reshape(-1) for p in params]).cpu()
+        torch.distributed.all_reduce(flat)
+        flat = (flat / self.world).to(self.device)
+        o = 0
+        for p in params:
+            p.grad.copy_(flat[o:o + p.numel()].view_as(p.grad))
+            o += p.numel()
 
     def end_epoch(self):
         """Step the LR schedule: once per epoch, as Lightning does for main.py:89-95."""
         self.scheduler.step()
 
 
+class ModelTrainer(HeadTrainer):
+    """The whole ArTEMIS model (main.py:37-95 without Lightning): forward on 4 context frames and
+    the output times, L1 on the full-resolution output only (loss.py:17-18), Adamax, MultiStepLR;
+    DDP all-reduces the 29.09 M parameters' gradients."""
+
+    @staticmethod
+    def build(num_features, fused):
+        return ArTEMIS(num_inputs=4, joinType="concat", kernel_size=5, dilation=1, fused=fused)
+
+    def shard(self, batch):
+        frames, gt, t = batch
+        if gt.size(0) % self.world != 0:
+            raise ValueError(f"global batch {gt.size(0)} is not a multiple of the world size "
+                             f"{self.world}: DDP's gradient average would not be the global mean")
+        b, e = shard_bounds(gt.size(0), self.rank, self.world)
+        return [f[b:e] for f in frames], gt[b:e], t[b:e]
+
+    def step(self, global_batch):
+        frames, gt, t = self.shard(global_batch)
+        self.optimizer.zero_grad(set_to_none=True)
+        _, _, out = self.model(frames, t)
+        loss = self.loss(out, gt)
+        loss.backward()
+        self.average_gradients()
+        self.optimizer.step()
+        return loss.detach()
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     add_device_argument(ap)
+    ap.add_argument("--model", choices=["head", "artemis"], default="head")
     ap.add_argument("--steps", type=int, default=3, help="optimizer steps per epoch")
     ap.add_argument("--epochs", type=int, default=1)
     ap.add_argument("--batch", type=int, default=8, help="global batch (sharded over ranks)")
@@ -94,6 +160,9 @@ def main(argv=None):
     ap.add_argument("--composed", action="store_true", help="reference composition instead of the fused head")
     ap.add_argument("--dump", default="", help="rank 0 writes the final parameters here (tests)")
     args = ap.parse_args(argv)
+    if os.environ.get("ARTEMIS_TRACE_HANG"):      # debugging aid: where is every thread after N s?
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["ARTEMIS_TRACE_HANG"]), exit=True)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1 and args.backend != "nccl" and args.device == "auto":
@@ -103,9 +172,14 @@ def main(argv=None):
     if world > 1:
         kw = {"device_id": device} if args.backend == "nccl" else {}
         torch.distributed.init_process_group(args.backend, **kw)
-    tr = HeadTrainer(device, num_features=args.features, fused=not args.composed)
+    full = args.model == "artemis"
+    tr = (ModelTrainer if full else HeadTrainer)(device, num_features=args.features,
+                                                 fused=not args.composed)
     for i in range(args.steps * args.epochs):
-        batch = synthetic_batch(args.batch, args.features, (args.size, args.size), 1000 + i, device)
+        if full:
+            batch = synthetic_frames(args.batch, (args.size, args.size), 1000 + i, device)
+        else:
+            batch = synthetic_batch(args.batch, args.features, (args.size, args.size), 1000 + i, device)
         loss = tr.step(batch)
         if (i + 1) % args.steps == 0:
             tr.end_epoch()

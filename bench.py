@@ -8,17 +8,25 @@ context frames one `artemis_synth_forward`, then for each frame one `artemis_syn
 model/chrono_synth.py:120-126) -- what one ChronoSynth head does per training step for
 `batch` samples of 1080 x 1920.  A *synthesized pixel* is one (n, y, x) of that head
 (SURVEY.md 8d).  Operands are resident in HBM before the timed region; the kernels are called
-through the C ABI on torch's current stream with preallocated outputs.
+through the C ABI on torch's current stream with preallocated outputs, with the LIBRARY DEFAULT
+tile radius (what a caller of FunctionSynth gets).
 
 Multi-GPU: the op shards by batch x timestep with no data-path collective (every output element
 depends only on its own sample, cupy_module/synth.py:19), so every rank runs the same per-GPU
 workload on its own shard (weak scaling) and `value` = pixels of all ranks / max-over-ranks time.
+
+`--workload interp7` is BASELINE.json configs[3] instead (interpolate mode: one 4-frame window,
+7 timesteps, forward only): the 7 timesteps are dealt to the ranks with sharding.shard_items and
+each rank runs ITS timesteps as one fused-head launch -- all 7 in one launch on 1 GPU, one per GPU
+on 8 GPUs with one rank idle (strong scaling; `value` = 7 x 1080p pixels / max-over-ranks time).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 """
 import argparse
+import ctypes
+import hashlib
 import json
 import os
 import sys
@@ -36,21 +44,45 @@ PAD = 2
 # algorithmic (compulsory) bytes per pixel per frame, fp32: SURVEY.md 8d / DESIGN.md
 FWD_BYTES = 3 * K_TAPS * 4 + C * 4 + C * 4 * (H + 2 * PAD) * (W + 2 * PAD) / (H * W)
 BWD_BYTES = 3 * K_TAPS * 4 + 3 * K_TAPS * 4 + C * 4 + C * 4 * (H + 2 * PAD) * (W + 2 * PAD) / (H * W)
+# fused head, forward, per head pixel (T = 4 frames read in place + occlusion, one output)
+HEAD_FWD_BYTES = FRAMES * (3 * K_TAPS * 4 + C * 4 + 4) + C * 4
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def make_frames(batch, sigma, device, seed):
+def make_offsets(regime, shape, device, g):
+    """Offset regimes: 'sigma:<s>' i.i.d. N(0, s^2) per pixel and tap (the headline
+    is sigma:1); 'smooth30' = one low-frequency flow field of about +-30 px shared by the 25 taps
+    (control points every ~128 px, N(0, 15^2), bicubic) + 0.3 px noise, vertical and horizontal
+    fields independent -- large coherent motion with steep gradients; 'pan' = every tap displaced
+    by (20, -35) px + N(0, 1)."""
+    N, K, h, w = shape
+    rn = lambda *s: torch.randn(*s, device=device, generator=g)
+    if regime.startswith("sigma:"):
+        s = float(regime.split(":")[1])
+        return rn(N, K, h, w) * s, rn(N, K, h, w) * s
+    if regime == "smooth30":
+        lo_y = rn(N, 1, h // 128 + 2, w // 128 + 2) * 15
+        lo_x = rn(N, 1, h // 128 + 2, w // 128 + 2) * 15
+        up = lambda lo: torch.nn.functional.interpolate(lo, size=(h, w), mode="bicubic").expand(N, K, h, w)
+        return ((up(lo_y) + rn(N, K, h, w) * 0.3).contiguous(),
+                (up(lo_x) + rn(N, K, h, w) * 0.3).contiguous())
+    if regime == "pan":
+        return (rn(N, K, h, w) + 20.0).contiguous(), (rn(N, K, h, w) - 35.0).contiguous()
+    raise KeyError(regime)
+
+
+def make_frames(batch, sigma, device, seed, regime=None):
     """Synthetic operands per SURVEY.md 8d: frames rand in [0,1] replication-padded by 2, weights
-    softmax over 25 N(0,1) logits, offsets N(0, sigma^2), gradOutput randn."""
+    softmax over 25 N(0,1) logits, offsets per `regime` (default N(0, sigma^2)), gradOutput randn."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
+    regime = regime or f"sigma:{sigma}"
     frames = []
     for _ in range(FRAMES):
         frame = torch.rand(batch, C, H, W, device=device, generator=g)
         inp = torch.nn.functional.pad(frame, (PAD,) * 4, mode="replicate").contiguous()
         w = torch.softmax(torch.randn(batch, K_TAPS, H, W, device=device, generator=g), 1)
-        oy = torch.randn(batch, K_TAPS, H, W, device=device, generator=g) * sigma
-        ox = torch.randn(batch, K_TAPS, H, W, device=device, generator=g) * sigma
+        oy, ox = make_offsets(regime, (batch, K_TAPS, H, W), device, g)
         gout = torch.randn(batch, C, H, W, device=device, generator=g)
         out = torch.empty(batch, C, H, W, device=device)
         gw, ga, gb = (torch.empty(batch, K_TAPS, H, W, device=device) for _ in range(3))
@@ -58,24 +90,30 @@ def make_frames(batch, sigma, device, seed):
     return frames
 
 
+def _cpu_operands(rng, n, h, w, sigma):
+    import numpy as np
+    shape = (n, K_TAPS, h, w)
+    inp = rng.random((n, C, h + 2 * PAD, w + 2 * PAD), dtype=np.float32)
+    logits = rng.standard_normal(shape, dtype=np.float32)
+    e = np.exp(logits)
+    wt = (e / e.sum(1, keepdims=True)).astype(np.float32)
+    oy = rng.standard_normal(shape, dtype=np.float32) * np.float32(sigma)
+    ox = rng.standard_normal(shape, dtype=np.float32) * np.float32(sigma)
+    gout = rng.standard_normal((n, C, h, w), dtype=np.float32)
+    return inp, wt, oy, ox, gout
+
+
 def cpu_baseline(threads, sigma):
     """The oracle's C restatement (kind "port": the reference has no CPU path and cannot be
-    built here) timed on the host cores for one full step of the same workload at batch 1."""
+    built here) timed on the host cores for whole steps of the same workload at batch 1, plus --
+    as BASELINE.md's CPU-baseline plan asks -- the PyTorch transcription on the same step and both
+    on configs[1] (N = 16, 256 x 448, 4 frames, forward only), each on a bounded sample."""
     import numpy as np
     from oracle import synth_oracle as so
     so.set_threads(threads)
+    torch.set_num_threads(threads)
     rng = np.random.default_rng(103)
-    shape = (1, K_TAPS, H, W)
-    sets = []
-    for _ in range(FRAMES):
-        inp = rng.random((1, C, H + 2 * PAD, W + 2 * PAD), dtype=np.float32)
-        logits = rng.standard_normal(shape, dtype=np.float32)
-        e = np.exp(logits)
-        w = (e / e.sum(1, keepdims=True)).astype(np.float32)
-        oy = rng.standard_normal(shape, dtype=np.float32) * np.float32(sigma)
-        ox = rng.standard_normal(shape, dtype=np.float32) * np.float32(sigma)
-        gout = rng.standard_normal((1, C, H, W), dtype=np.float32)
-        sets.append((inp, w, oy, ox, gout))
+    sets = [_cpu_operands(rng, 1, H, W, sigma) for _ in range(FRAMES)]
     # whole steps until about 10 s of CPU work (at least 1, at most 12 steps)
     t_total, steps = 0.0, 0
     while steps < 1 or (t_total < 10.0 and steps < 12):
@@ -87,14 +125,64 @@ def cpu_baseline(threads, sigma):
             so.grad_beta(gout, inp, w, oy, ox, 1)
             t_total += time.perf_counter() - t0
         steps += 1
-    return {
+    res = {
         "value": round(steps * H * W / 1e6 / t_total, 3),
         "unit": "Mpix/s",
         "cores": threads,
+        "host_cpus": os.cpu_count(),
         "kind": "port",
         "sample": f"{steps} steps of {FRAMES} frames x 1080x1920, batch 1, fwd + gradWeight/Alpha/Beta, "
-                  f"oracle/synth_oracle.c (gcc -O2, OpenMP, {threads} threads), {t_total:.1f} s",
+                  f"oracle/synth_oracle.c (gcc -O2, OpenMP, {threads} threads of "
+                  f"{os.cpu_count()} host cpus), {t_total:.1f} s",
     }
+    # the same step through the vectorised PyTorch transcription (forward + autograd backward to
+    # weight/offsets): ONE frame, scaled to a 4-frame step
+    t = [torch.from_numpy(a) for a in sets[0]]
+    t0 = time.perf_counter()
+    leaves = [x.clone().requires_grad_(True) for x in t[1:4]]
+    so.forward_torch(t[0], *leaves, 1).backward(t[4])
+    dt = time.perf_counter() - t0
+    res["torch_transcription"] = {
+        "value": round(H * W / 1e6 / (dt * FRAMES), 3), "unit": "Mpix/s", "cores": threads,
+        "sample": f"1 frame of 1080x1920 fwd + autograd bwd (oracle.forward_torch), {dt:.1f} s, x{FRAMES} "
+                  "frames per step"}
+    # configs[1]: N = 16, 256 x 448, 4 frames, forward only
+    n2, h2, w2 = 16, 256, 448
+    inp, wt, oy, ox, _ = _cpu_operands(rng, n2, h2, w2, sigma)
+    t0 = time.perf_counter()
+    reps = 0
+    while reps < 1 or (time.perf_counter() - t0 < 3.0 and reps < 8):
+        so.forward(inp, wt, oy, ox, 1)
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    tt = [torch.from_numpy(a) for a in (inp[:2], wt[:2], oy[:2], ox[:2])]
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        so.forward_torch(*tt, 1)
+    dtt = (time.perf_counter() - t0) * (n2 / 2)
+    res["config2_forward"] = {
+        "workload": "N=16, 256x448, 4 frames, forward only (BASELINE.json configs[1])",
+        "unit": "Mpix/s (synthesized: 4 frame calls per pixel)",
+        "port": round(n2 * h2 * w2 / 1e6 / (dt * FRAMES), 3),
+        "torch_transcription": round(n2 * h2 * w2 / 1e6 / (dtt * FRAMES), 3),
+        "sample": f"port: {reps} x one frame call of all 16 samples ({dt:.2f} s each); transcription: "
+                  f"2 of 16 samples once, scaled; both x{FRAMES} frames",
+    }
+    return res
+
+
+def head_operands(B, device, regime, seed):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    T = FRAMES
+    frames = [torch.rand(B, C, H, W, device=device, generator=g) for _ in range(T)]
+    w = torch.softmax(torch.randn(B, T, K_TAPS, H, W, device=device, generator=g), 2)
+    ab = [make_offsets(regime, (B, K_TAPS, H, W), device, g) for _ in range(T)]
+    a = torch.stack([p[0] for p in ab], 1).contiguous()
+    b = torch.stack([p[1] for p in ab], 1).contiguous()
+    occ = torch.softmax(torch.randn(B, T, H, W, device=device, generator=g), 1)
+    gout = torch.randn(B, C, H, W, device=device, generator=g)
+    return frames, w, a, b, occ, gout
 
 
 def head_timing(device, radius, sigma, iters=20):
@@ -106,21 +194,13 @@ def head_timing(device, radius, sigma, iters=20):
     import artemis_amd
     lib = _lib.load()
     stream = torch.cuda.current_stream().cuda_stream
-    g = torch.Generator(device=device)
-    g.manual_seed(7)
     res = {}
     for B in (1, 2):
         T = FRAMES
-        frames = [torch.rand(B, C, H, W, device=device, generator=g) for _ in range(T)]
-        w = torch.softmax(torch.randn(B, T, K_TAPS, H, W, device=device, generator=g), 2)
-        a = torch.randn(B, T, K_TAPS, H, W, device=device, generator=g) * sigma
-        b = torch.randn(B, T, K_TAPS, H, W, device=device, generator=g) * sigma
-        occ = torch.softmax(torch.randn(B, T, H, W, device=device, generator=g), 1)
-        gout = torch.randn(B, C, H, W, device=device, generator=g)
+        frames, w, a, b, occ, gout = head_operands(B, device, f"sigma:{sigma}", 7 + B)
         out = torch.empty(B, C, H, W, device=device)
         gw, ga, gb = (torch.empty_like(w) for _ in range(3))
         gocc = torch.empty_like(occ)
-        import ctypes
         ptrs = (ctypes.c_void_p * T)(*[f.data_ptr() for f in frames])
 
         def fused():
@@ -164,16 +244,264 @@ def head_timing(device, radius, sigma, iters=20):
     return res
 
 
+def source_hash():
+    """Hash of the kernel sources: recorded PMC traffic is only quoted for the build it was taken on."""
+    h = hashlib.sha256()
+    for name in ("synth_device.hpp", "synth_tiles.hip", "synth_kernels.hip"):
+        with open(os.path.join(ROOT, "artemis_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def recorded_traffic(key, batch):
+    """HBM bytes per launch from the rocprofv3 PMC passes recorded in profiles/pmc_traffic.json
+    (counters cannot be read inside this process); None unless recorded for these kernel sources."""
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        rec = json.load(open(tpath))
+    except Exception:
+        return None, None
+    if rec.get("source_hash") != source_hash():
+        return None, "profiles/pmc_traffic.json was recorded for other kernel sources"
+    v = rec.get(key)
+    return (None if v is None else int(v) * batch), "profiles/pmc_traffic.json (rocprofv3 --pmc, recorded)"
+
+
+class Op:
+    """fwd / bwd launchers of one operand set list through the C ABI."""
+
+    def __init__(self, lib, frames, B, radius, stream):
+        self.lib, self.frames, self.B, self.radius, self.stream = lib, frames, B, radius, stream
+
+    def fwd(self, f):
+        _lib.check(self.lib.artemis_synth_forward(
+            f["inp"].data_ptr(), f["w"].data_ptr(), f["oy"].data_ptr(), f["ox"].data_ptr(),
+            f["out"].data_ptr(), self.B, C, H, W, 5, 1, self.radius, self.stream), "forward")
+
+    def bwd(self, f):
+        _lib.check(self.lib.artemis_synth_backward(
+            f["inp"].data_ptr(), f["w"].data_ptr(), f["oy"].data_ptr(), f["ox"].data_ptr(),
+            f["gout"].data_ptr(), None, f["gw"].data_ptr(), f["ga"].data_ptr(),
+            f["gb"].data_ptr(), self.B, C, H, W, 5, 1, _lib.GIN_ATOMIC, self.radius, None, 0,
+            self.stream), "backward")
+
+    def step(self, events=None):
+        # one event pair around the 4 forward launches and one around the 4 backward launches:
+        # per-launch averages without an event between every two kernels
+        if events is not None:
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            e0.record()
+        for f in self.frames:
+            self.fwd(f)
+        if events is not None:
+            e1.record()
+        for f in self.frames:
+            self.bwd(f)
+        if events is not None:
+            e2.record()
+            events.append((e0, e1, e2))
+
+
+def regime_timing(lib, device, B, radius, stream, regime, steps, headline_mpix):
+    """The same step under another offset regime (few steps, HIP events)."""
+    frames = make_frames(B, 0.0, device, seed=211, regime=regime)
+    op = Op(lib, frames, B, radius, stream)
+    for _ in range(2):
+        op.step()
+    ev = []
+    for _ in range(steps):
+        op.step(ev)
+    torch.cuda.synchronize()
+    fwd = sum(a.elapsed_time(b) for a, b, _ in ev) / (len(ev) * FRAMES)
+    bwd = sum(b.elapsed_time(c) for _, b, c in ev) / (len(ev) * FRAMES)
+    mpix = B * H * W / ((fwd + bwd) * FRAMES * 1e-3) / 1e6
+    del frames, op
+    torch.cuda.empty_cache()
+    return {"Mpix_s": round(mpix, 1), "fwd_kernel_ms": round(fwd, 4), "bwd_kernel_ms": round(bwd, 4),
+            "vs_headline": round(mpix / headline_mpix, 3)}
+
+
+def run_train(args, rank, world, device, dist, backend):
+    lib = _lib.load()  # raises if the HIP library is missing: there is no fallback
+    B = args.batch
+    frames = make_frames(B, args.sigma, device, seed=103 + rank)
+    stream = torch.cuda.current_stream().cuda_stream
+    op = Op(lib, frames, B, args.radius, stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    events = []
+    for _ in range(args.warmup):
+        op.step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        op.step(events)
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+
+    ms = (t1 - t0) * 1e3 / args.steps
+    if world > 1:
+        tt = torch.tensor([ms], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ms = float(tt.item())
+    if rank != 0:
+        return None
+    pix_per_step = world * B * H * W
+    value = pix_per_step / (ms * 1e-3) / 1e6
+    fwd_ms = sum(a.elapsed_time(b) for a, b, _ in events) / (len(events) * FRAMES)
+    bwd_ms = sum(b.elapsed_time(c) for _, b, c in events) / (len(events) * FRAMES)
+    bwd_gbs = BWD_BYTES * B * H * W / (bwd_ms * 1e-3) / 1e9
+    fwd_gbs = FWD_BYTES * B * H * W / (fwd_ms * 1e-3) / 1e9
+    traffic, traffic_src = recorded_traffic("synth_bwd_bytes_per_launch", B)
+    line = {
+        "metric": "synthesized Mpix/s fwd+bwd (4 frames, 1080p)",
+        "value": round(value, 2),
+        "unit": "Mpix/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "synth op fwd+bwd (gradWeight, gradOffset_y, gradOffset_x), 4 frames x "
+                        "1080x1920, k=5 d=1 C=3, fp32",
+            "batch_per_gpu": B,
+            "offset_regime": f"sigma:{args.sigma:g} (i.i.d. N(0, sigma^2) px per pixel and tap)",
+            "tile_radius": args.radius,
+            "tile_radius_note": "-1 = the library default (what FunctionSynth callers get)",
+            "sharding": "batch x timestep, no collective",
+            "hbm_frac_of_8TBps_whole_step": round(
+                value * 1e6 * (FWD_BYTES + BWD_BYTES) * FRAMES / world / 1e9 / HBM_PEAK_GBS, 4),
+            "fwd_kernel_ms": round(fwd_ms, 4),
+            "fwd_kernel_GBps": round(fwd_gbs, 1),
+        },
+        "roofline": {
+            "kernel": "synth_bwd_tapmajor (fused gradWeight/gradOffset_y/gradOffset_x)",
+            "bound": "hbm",
+            "achieved": round(bwd_gbs, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(bwd_gbs / HBM_PEAK_GBS, 4),
+            "traffic": traffic,
+            "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": round(BWD_BYTES * B * H * W),
+            "avg_launch_ms": round(bwd_ms, 4),
+        },
+    }
+    if world == 1:
+        del frames, op
+        torch.cuda.empty_cache()
+        if args.regimes:
+            line["config"]["other_offset_regimes"] = {
+                r: regime_timing(lib, device, B, args.radius, stream, r, 5, value)
+                for r in args.regimes.split(",")}
+        if not args.no_head:
+            line["config"]["chrono_head_fwd_bwd_1080p"] = head_timing(device, args.radius, args.sigma)
+        if not args.no_cpu_baseline:  # reported at N = 1 only
+            threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+            line["cpu_baseline"] = cpu_baseline(threads, args.sigma)
+    return line
+
+
+def run_interp7(args, rank, world, device, dist, backend):
+    """BASELINE.json configs[3]: interpolate mode, one 4-frame 1080p window, 7 timesteps
+    (main.py:114-121 runs them one model forward at a time).  Timesteps are dealt with
+    sharding.shard_items; a rank runs all of ITS timesteps as one fused-head forward launch."""
+    from artemis_amd.sharding import shard_items
+    lib = _lib.load()
+    stream = torch.cuda.current_stream().cuda_stream
+    TS = 7
+    items = shard_items(1, TS, rank, world)
+    n = len(items)
+    T = FRAMES
+    if n:
+        # the window's 4 frames are the same for every timestep; weights/offsets/occlusion differ
+        frames1, w, a, b, occ, _ = head_operands(n, device, f"sigma:{args.sigma}", 300 + rank)
+        frames = [f[:1].expand(n, C, H, W).contiguous() for f in frames1]
+        out = torch.empty(n, C, H, W, device=device)
+        ptrs = (ctypes.c_void_p * T)(*[f.data_ptr() for f in frames])
+
+    def step():
+        if n:
+            _lib.check(lib.artemis_synth_head_forward(
+                ptrs, T, w.data_ptr(), a.data_ptr(), b.data_ptr(), occ.data_ptr(), out.data_ptr(),
+                n, H, W, H, W, -2, -2, 0, args.radius, stream), "head_forward")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    ms = (t1 - t0) * 1e3 / args.steps
+    if world > 1:
+        tt = torch.tensor([ms], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ms = float(tt.item())
+    if rank != 0:
+        return None
+    kernel_ms = e0.elapsed_time(e1) / args.steps
+    value = TS * H * W / (ms * 1e-3) / 1e6
+    gbs = HEAD_FWD_BYTES * n * H * W / (kernel_ms * 1e-3) / 1e9
+    busy = min(world, TS)
+    return {
+        "metric": "synthesized Mpix/s fwd (interpolate: 7 timesteps, 4 frames, 1080p)",
+        "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": "interp7: fused ChronoSynth head forward, one 4-frame 1080x1920 window, 7 "
+                        "timesteps (BASELINE.json configs[3]), k=5 d=1 C=3, fp32",
+            "timesteps_on_rank0": n, "busy_ranks": busy, "idle_ranks": world - busy,
+            "offset_regime": f"sigma:{args.sigma:g}", "tile_radius": args.radius,
+            "sharding": "sharding.shard_items(1, 7, rank, world): timesteps dealt in balanced "
+                        "blocks, no collective",
+        },
+        "roofline": {
+            "kernel": "synth_fwd_tapmajor<HEAD> (fused 4-frame head forward), rank 0's launch",
+            "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            "algorithmic_bytes_per_launch": round(HEAD_FWD_BYTES * n * H * W),
+            "avg_launch_ms": round(kernel_ms, 4),
+        },
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=["train", "interp7"], default="train",
+                    help="train = the headline (op fwd+bwd, 4 frames, 1080p); interp7 = configs[3]")
     ap.add_argument("--batch", type=int, default=1, help="samples per GPU (1080p each)")
     ap.add_argument("--sigma", type=float, default=1.0, help="offset std in pixels (headline: 1)")
-    ap.add_argument("--radius", type=int, default=8,
-                    help="LDS tile radius; 8 serves |offset| < 9, ample for the headline sigma = 1 "
-                         "(library default 16 is 2-3 %% slower here and robust to sigma = 4)")
+    ap.add_argument("--radius", type=int, default=-1,
+                    help="LDS tile radius passed to the library; -1 = the library default")
+    ap.add_argument("--regimes", default="smooth30,sigma:4",
+                    help="other offset regimes timed beside the headline at N = 1 ('' = none)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, host cpus)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-head", action="store_true", help="skip the fused-head side measurement")
@@ -191,6 +519,7 @@ def main():
     dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
@@ -198,120 +527,9 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    lib = _lib.load()  # raises if the HIP library is missing: there is no fallback
-    frames = make_frames(args.batch, args.sigma, device, seed=103 + rank)
-    stream = torch.cuda.current_stream().cuda_stream
-    B = args.batch
-
-    def fwd(f):
-        _lib.check(lib.artemis_synth_forward(
-            f["inp"].data_ptr(), f["w"].data_ptr(), f["oy"].data_ptr(), f["ox"].data_ptr(),
-            f["out"].data_ptr(), B, C, H, W, 5, 1, args.radius, stream), "forward")
-
-    def bwd(f):
-        _lib.check(lib.artemis_synth_backward(
-            f["inp"].data_ptr(), f["w"].data_ptr(), f["oy"].data_ptr(), f["ox"].data_ptr(),
-            f["gout"].data_ptr(), None, f["gw"].data_ptr(), f["ga"].data_ptr(),
-            f["gb"].data_ptr(), B, C, H, W, 5, 1, _lib.GIN_ATOMIC, args.radius, None, 0, stream),
-            "backward")
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
-    bwd_events, fwd_events = [], []
-
-    def step(record):
-        # one event pair around the 4 forward launches and one around the 4 backward launches:
-        # per-launch averages without an event between every two kernels
-        if record:
-            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-            e0.record()
-        for f in frames:
-            fwd(f)
-        if record:
-            e1.record()
-        for f in frames:
-            bwd(f)
-        if record:
-            e2.record()
-            fwd_events.append((e0, e1))
-            bwd_events.append((e1, e2))
-
-    for _ in range(args.warmup):
-        step(False)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    torch.cuda.synchronize()
-    barrier()
-    t1 = time.perf_counter()
-
-    ms = (t1 - t0) * 1e3 / args.steps
-    if world > 1:
-        tt = torch.tensor([ms], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        ms = float(tt.item())
-
+    run = run_train if args.workload == "train" else run_interp7
+    line = run(args, rank, world, device, dist, backend)
     if rank == 0:
-        pix_per_step = world * B * H * W
-        value = pix_per_step / (ms * 1e-3) / 1e6
-        bwd_ms = sum(a.elapsed_time(b) for a, b in bwd_events) / (len(bwd_events) * FRAMES)
-        fwd_ms = sum(a.elapsed_time(b) for a, b in fwd_events) / (len(fwd_events) * FRAMES)
-        bwd_gbs = BWD_BYTES * B * H * W / (bwd_ms * 1e-3) / 1e9
-        fwd_gbs = FWD_BYTES * B * H * W / (fwd_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("synth_bwd_bytes_per_launch")
-            except Exception:
-                traffic = None
-        line = {
-            "metric": "synthesized Mpix/s fwd+bwd (4 frames, 1080p)",
-            "value": round(value, 2),
-            "unit": "Mpix/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(ms, 4),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {
-                "workload": "synth op fwd+bwd (gradWeight, gradOffset_y, gradOffset_x), 4 frames x "
-                            "1080x1920, k=5 d=1 C=3, fp32",
-                "batch_per_gpu": B,
-                "offset_sigma_px": args.sigma,
-                "tile_radius": args.radius,
-                "sharding": "batch x timestep, no collective",
-                "hbm_frac_of_8TBps_whole_step": round(
-                    value * 1e6 * (FWD_BYTES + BWD_BYTES) * FRAMES / world / 1e9 / HBM_PEAK_GBS, 4),
-                "fwd_kernel_ms": round(fwd_ms, 4),
-                "fwd_kernel_GBps": round(fwd_gbs, 1),
-            },
-            "roofline": {
-                "kernel": "synth_bwd_tapmajor (fused gradWeight/gradOffset_y/gradOffset_x)",
-                "bound": "hbm",
-                "achieved": round(bwd_gbs, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(bwd_gbs / HBM_PEAK_GBS, 4),
-                "traffic": traffic,
-                "algorithmic_bytes_per_launch": round(BWD_BYTES * B * H * W),
-                "avg_launch_ms": round(bwd_ms, 4),
-            },
-        }
-        if world == 1 and not args.no_head:
-            line["config"]["chrono_head_fwd_bwd_1080p"] = head_timing(device, args.radius, args.sigma)
-        if world == 1 and not args.no_cpu_baseline:  # reported at N = 1 only
-            threads = args.cpu_threads or min(16, os.cpu_count() or 1)
-            line["cpu_baseline"] = cpu_baseline(threads, args.sigma)
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

@@ -1,0 +1,352 @@
+"""The ArTEMIS harness around the hot path (artemis_amd/model/{artemis,encoder,chrono_synth}.py):
+stock PyTorch ops + the fused head op, state-dict compatible with upstream.
+
+The reference model cannot be built here (model/chrono_synth.py:66 imports cupy_module.synth, which
+imports CuPy; model/sep_sts_layer.py:4 imports timm -- neither is installed), so the restatement is
+checked against (a) a key/shape table derived by hand from the reference's layer definitions
+(model/artemis.py:22-48, model/sep_sts_encoder.py:36-50, model/sep_sts_layer.py:127-129,170-173,
+251-260, model/chrono_synth.py:12-75, model/helper_modules.py:8-9,42-43) with the parameter count the
+survey measured on the reference itself (29,090,528; synthesis heads 960,960: SURVEY.md 8c), (b)
+independent restatements of the two non-obvious pieces (shift mask, attention), and (c) a committed
+config-1 fixture of this restatement (tests/golden/model/config1_cpu_forward.npz: BASELINE configs[0];
+parity unpinned -- it freezes this build's numbers, not the reference's).
+"""
+import os
+import subprocess
+import sys
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIXTURE = os.path.join(ROOT, "tests", "golden", "model", "config1_cpu_forward.npz")
+
+
+# ------------------------------------------------------------------ (a) key / shape table
+
+def expected_state_dict():
+    """{key: shape}, written out from the reference's constructors."""
+    sd = {}
+
+    def conv(key, cout, cin, *k, bias=True):
+        sd[key + ".weight"] = (cout, cin, *k)
+        if bias:
+            sd[key + ".bias"] = (cout,)
+
+    def convT(key, cin, cout, *k):
+        sd[key + ".weight"] = (cin, cout, *k)
+        sd[key + ".bias"] = (cout,)
+
+    def linear(key, cout, cin):
+        sd[key + ".weight"] = (cout, cin)
+        sd[key + ".bias"] = (cout,)
+
+    def resblock(key, c):                                     # sep_sts_encoder.py:19-20
+        conv(key + ".conv1", c, c, 3, 3, 3)
+        conv(key + ".conv2", c, c, 3, 3, 3)
+
+    def attention(key, dim, window, heads):                   # sep_sts_layer.py:127-129,166,170,173
+        n = window[0] * window[1] * window[2]
+        table = (2 * window[0] - 1) * (2 * window[1] - 1) * (2 * window[2] - 1)
+        sd[key + ".relative_position_bias_table"] = (table, heads)
+        sd[key + ".relative_position_indices"] = (n, n)       # a buffer, saved with the weights
+        linear(key + ".qkv", 3 * dim, dim)
+        linear(key + ".project", dim, dim)
+
+    # encoder (sep_sts_encoder.py:36-50): nf = [512, 256, 128, 64], NF = 4, heads [2, 4, 8, 16]
+    conv("encoder.stem.0", 32, 3, 3, 3, 3)
+    resblock("encoder.stem.2", 32)
+    for stage, (dim, depth, heads) in enumerate([(64, 2, 2), (128, 2, 4), (256, 6, 8), (512, 2, 16)], 1):
+        for b in range(depth):
+            key = f"encoder.stage{stage}.upper.blocks.{b}"
+            sd[key + ".norm1.weight"] = sd[key + ".norm1.bias"] = (dim,)
+            attention(key + ".depth_attn", dim, (1, 8, 8), heads)
+            attention(key + ".point_attn", dim, (4, 1, 1), heads)
+            sd[key + ".norm2.weight"] = sd[key + ".norm2.bias"] = (dim,)
+            linear(key + ".mlp.linear1", 4 * dim, dim)
+            linear(key + ".mlp.linear2", dim, 4 * dim)
+    for i, (cin, cout) in enumerate([(32, 64), (64, 128), (128, 256), (256, 512)]):
+        conv(f"encoder.down{i}", cout, cin, 3, 3, 3)
+    # decoder (artemis.py:25-29, helper_modules.py:8-9), joinType concat: growth 2
+    for i, (cin, cout) in enumerate([(512, 256), (512, 128), (256, 64)]):
+        convT(f"decoder.{i}.upconv", cin, cout, 3, 3, 3)
+    # SmoothNets (artemis.py:31-41)
+    for i, cin in enumerate([512, 256, 128], 1):
+        conv(f"smooth{i}.0.conv.0", 64, cin, 3, 3, 3)
+        resblock(f"smooth{i}.1", 64)
+    # ChronoSynth heads (chrono_synth.py:12-75): 65 = 64 features + the time channel
+    for i in (1, 2, 3):
+        for name, mid, out in (("ModuleWeight", 25, 25), ("ModuleAlpha", 25, 25),
+                               ("ModuleBeta", 25, 25), ("ModuleOcclusion", 64, 4)):
+            key = f"predict{i}.{name}"
+            conv(key + ".0", 64, 65, 3, 3)
+            conv(key + ".2", mid, 64, 3, 3)
+            convT(key + ".4", mid, mid, 3, 3)
+            conv(key + ".5", out, mid, 3, 3)
+        conv(f"predict{i}.feature_fuse.conv.0", 65, 260, 1, 1)
+    return sd
+
+
+def test_state_dict_keys_shapes_and_parameter_count():
+    from artemis_amd.model import ArTEMIS
+    want = expected_state_dict()
+    model = ArTEMIS(num_inputs=4, joinType="concat", kernel_size=5, dilation=1)
+    got = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert sorted(got) == sorted(want)
+    assert got == want
+    params = {k for k, _ in model.named_parameters()}
+    n_params = sum(int(np.prod(want[k])) for k in params)
+    assert n_params == 29_090_528
+    assert sum(int(np.prod(want[k])) for k in params if k.startswith("predict")) == 960_960
+    assert all(k.endswith("relative_position_indices") for k in set(want) - params)
+
+
+# ------------------------------------------------------------------ (b) independent restatements
+
+def slicing_mask(size, ws, shift):
+    """The textbook construction (assignment through negative slices), for comparison."""
+    img = torch.zeros((1, *size, 1))
+    cnt = 0
+    for d in (slice(-ws[0]), slice(-ws[0], -shift[0]), slice(-shift[0], None)):
+        for h in (slice(-ws[1]), slice(-ws[1], -shift[1]), slice(-shift[1], None)):
+            for w in (slice(-ws[2]), slice(-ws[2], -shift[2]), slice(-shift[2], None)):
+                img[:, d, h, w, :] = cnt
+                cnt += 1
+    from artemis_amd.model.encoder import _windows
+    m = _windows(img, ws).squeeze(-1)
+    diff = m.unsqueeze(1) - m.unsqueeze(2)
+    return diff.masked_fill(diff != 0, -100.0).masked_fill(diff == 0, 0.0)
+
+
+@pytest.mark.parametrize("size,ws,shift", [((4, 16, 16), (1, 8, 8), (0, 4, 4)), ((4, 8, 24), (1, 8, 8), (0, 0, 4)),
+                                           ((4, 32, 16), (1, 8, 8), (0, 4, 4)), ((2, 16, 8), (2, 8, 8), (0, 4, 0))])
+def test_shift_mask_equals_slicing_construction(size, ws, shift):
+    from artemis_amd.model.encoder import _shift_mask
+    got = _shift_mask(size, ws, shift, torch.device("cpu"))
+    assert torch.equal(got, slicing_mask(size, ws, shift))
+
+
+def test_window_attention_equals_explicit_softmax():
+    from artemis_amd.model.encoder import WindowAttention3D
+    torch.manual_seed(0)
+    att = WindowAttention3D(32, (1, 4, 4), 4)
+    with torch.no_grad():
+        att.relative_position_bias_table.normal_(0, 0.5)
+    x = torch.randn(6, 16, 32)
+    mask = torch.zeros(3, 16, 16)
+    mask[1, :8, 8:] = -100.0
+    mask[1, 8:, :8] = -100.0
+    for m in (None, mask):
+        got = att(x, m)
+        qkv = att.qkv(x).reshape(6, 16, 3, 4, 8).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv[0] * 8 ** -0.5, qkv[1], qkv[2]
+        a = q @ k.transpose(-2, -1)
+        idx = att.relative_position_indices[:16, :16].reshape(-1)
+        a = a + att.relative_position_bias_table[idx].reshape(16, 16, -1).permute(2, 0, 1).unsqueeze(0)
+        if m is not None:
+            a = (a.view(2, 3, 4, 16, 16) + m.unsqueeze(1).unsqueeze(0)).view(-1, 4, 16, 16)
+        want = att.project((a.softmax(-1) @ v).transpose(1, 2).reshape(6, 16, 32))
+        torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+
+
+def test_relative_position_indices():
+    from artemis_amd.model.encoder import _relative_position_indices
+    idx = _relative_position_indices((1, 8, 8))
+    assert idx.shape == (64, 64) and int(idx.min()) == 0 and int(idx.max()) == 15 * 15 - 1
+    # token (h, w) attending to (h', w'): ((h - h') + 7) * 15 + ((w - w') + 7)
+    q, k = 3 * 8 + 5, 6 * 8 + 1
+    assert int(idx[q, k]) == (3 - 6 + 7) * 15 + (5 - 1 + 7)
+    t = _relative_position_indices((4, 1, 1))
+    assert t.shape == (4, 4) and [int(v) for v in t[0]] == [3, 2, 1, 0]
+
+
+# ------------------------------------------------------------------ (c) config 1 on the CPU
+
+class _OracleOp:
+    """FunctionSynth stand-in for CPU tensors: the oracle's differentiable torch restatement.
+    TEST ONLY -- the product raises NotImplementedError on CPU tensors like the reference."""
+    calls = []
+
+    @classmethod
+    def apply(cls, input, weight, offset_y, offset_x, dilation):
+        from oracle import synth_oracle
+        cls.calls.append((input, weight, offset_y, offset_x))
+        return synth_oracle.forward_torch(input, weight, offset_y, offset_x, dilation)
+
+
+def cpu_model(monkeypatch):
+    from artemis_amd.model import ArTEMIS, chrono_synth
+    monkeypatch.setattr(chrono_synth, "FunctionSynth", _OracleOp)
+    _OracleOp.calls = []
+    torch.manual_seed(103)                                      # config.py:62
+    return ArTEMIS(4, "concat", 5, 1, fused=False).eval()
+
+
+def checksum(t):
+    return zlib.crc32(np.ascontiguousarray(t.detach().numpy()).tobytes())
+
+
+def config1_run(monkeypatch):
+    model = cpu_model(monkeypatch)
+    frames = [torch.rand(1, 3, 64, 64) for _ in range(4)]
+    with torch.no_grad():
+        outs = model(frames, torch.tensor([0.5]))
+    return model, frames, outs
+
+
+def test_config1_cpu_forward(monkeypatch):
+    """BASELINE configs[0]: ArTEMIS forward on CPU, random init (seed 103), batch 1, 4 x 3 x 64 x 64,
+    t = 0.5, synth via the CPU transcription: 12 op calls with operands (1,3,{20,36,68}^2) /
+    (1,25,{16,32,64}^2) and 3 outputs, against the committed fixture."""
+    model, frames, outs = config1_run(monkeypatch)
+    assert len(_OracleOp.calls) == 12
+    shapes = [(tuple(c[0].shape), tuple(c[1].shape)) for c in _OracleOp.calls]
+    for head, hw in enumerate((16, 32, 64)):
+        for f in range(4):
+            assert shapes[head * 4 + f] == ((1, 3, hw + 4, hw + 4), (1, 25, hw, hw))
+    assert [tuple(o.shape) for o in outs] == [(1, 3, 16, 16), (1, 3, 32, 32), (1, 3, 64, 64)]
+    # offsets at random init are tiny (|.| < 0.13), weights of head 1 a softmax
+    w1 = _OracleOp.calls[0][1]
+    torch.testing.assert_close(w1.sum(1), torch.ones_like(w1.sum(1)), rtol=1e-5, atol=1e-5)
+    assert max(float(c[2].abs().max()) for c in _OracleOp.calls) < 0.5
+    if not os.path.exists(FIXTURE):
+        pytest.skip("fixture missing: run tests/golden/model/make_config1.py")
+    with np.load(FIXTURE) as z:
+        for name, o in zip(("out_ll", "out_l", "out"), outs):
+            np.testing.assert_allclose(o.numpy(), z[name], rtol=1e-4, atol=1e-5, err_msg=name)
+        # operand statistics of the 12 calls (means of |.|: robust to last-bit differences between
+        # CPU conv algorithms; exact checksums are recorded in the fixture for the generating host)
+        stats = np.array([[float(t.abs().mean()) for t in c] for c in _OracleOp.calls], np.float64)
+        np.testing.assert_allclose(stats, z["operand_abs_means"], rtol=1e-3)
+
+
+def test_interpolate_batches_timesteps(monkeypatch):
+    """All timesteps of a window in one batch == the reference's one forward per timestep."""
+    model = cpu_model(monkeypatch)
+    frames = [torch.rand(1, 3, 32, 40) for _ in range(4)]
+    ts = [0.125, 0.5, 0.875]
+    batched = model.interpolate(frames, ts)
+    assert batched.shape == (3, 3, 32, 40)
+    with torch.no_grad():
+        for i, t in enumerate(ts):
+            single = model(frames, torch.tensor(t))[2]          # main.py:121 passes a 0-d tensor
+            torch.testing.assert_close(batched[i:i + 1], single, rtol=1e-4, atol=1e-5)
+
+
+def test_odd_sizes_follow_ceil_halving(monkeypatch):
+    model = cpu_model(monkeypatch)
+    frames = [torch.rand(1, 3, 36, 52) for _ in range(4)]     # 1/2: 18 x 26, 1/4: 9 x 13
+    with torch.no_grad():
+        ll, l, out = model(frames, torch.tensor([0.25]))
+    assert tuple(ll.shape[-2:]) == (9, 13) and tuple(l.shape[-2:]) == (18, 26)
+    assert tuple(out.shape[-2:]) == (36, 52)
+
+
+def test_main_cli_rejects_missing_frames_and_parses_devices():
+    from artemis_amd import main as entry
+    args = entry.get_args(["--mode", "interpolate", "--timesteps", "0.25, 0.5,0.75", "--device", "hip:3"])
+    assert args.device == "hip:3" and args.kernel_size == 5 and args.dilation == 1 and args.nbr_frame == 4
+    assert [float(t) for t in "".join(args.timesteps.split()).split(",")] == [0.25, 0.5, 0.75]
+
+
+# ------------------------------------------------------------------ GPU: the model on the HIP op
+
+@pytest.mark.gpu
+def test_full_model_fused_equals_composed_on_gpu():
+    """ArTEMIS on the device, fused head op vs the reference's per-frame composition around
+    FunctionSynth: same weights, same inputs; outputs within the forward tolerance, parameter
+    gradients within the backward tolerance."""
+    from artemis_amd.model import ArTEMIS
+    dev = torch.device("cuda:0")
+    torch.manual_seed(103)
+    fused = ArTEMIS(fused=True).to(dev)
+    composed = ArTEMIS(fused=False).to(dev)
+    composed.load_state_dict(fused.state_dict())
+    g = torch.Generator().manual_seed(1)
+    frames = [torch.rand(2, 3, 96, 128, generator=g).to(dev) for _ in range(4)]
+    gt = torch.rand(2, 3, 96, 128, generator=g).to(dev)
+    t = torch.tensor([0.25, 0.75], device=dev)
+    outs = []
+    for m in (fused, composed):
+        ll, l, out = m(frames, t)
+        torch.nn.functional.l1_loss(out, gt).backward()
+        outs.append((ll, l, out))
+    # (the head itself is bit-equal to the composition on identical operands, tests/test_model.py
+    # and test_head.py; here the two models run their convolutions separately, and MIOpen does not
+    # promise bit-equal results between two runs, so the outputs are compared to 1e-5 of their scale)
+    for a, b in zip(*outs):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+    worst = 0.0
+    for (k, p), (_, q) in zip(fused.named_parameters(), composed.named_parameters()):
+        scale = float(q.grad.abs().max())
+        err = float((p.grad - q.grad).abs().max())
+        worst = max(worst, err / max(scale, 1e-12))
+        assert err <= 1e-4 * max(scale, 1e-8), (k, err, scale)
+    print(f"fused vs composed: worst relative parameter-gradient difference {worst:.2e}")
+
+
+@pytest.mark.gpu
+def test_interpolate_seven_timesteps_on_gpu():
+    """BASELINE configs[3] at model level (small frame): 7 timesteps in one batch == 7 forwards."""
+    from artemis_amd.model import ArTEMIS
+    dev = torch.device("cuda:0")
+    torch.manual_seed(103)
+    model = ArTEMIS().to(dev).eval()
+    g = torch.Generator().manual_seed(2)
+    frames = [torch.rand(1, 3, 72, 120, generator=g).to(dev) for _ in range(4)]
+    ts = [i / 8 for i in range(1, 8)]
+    batched = model.interpolate(frames, ts)
+    assert batched.shape == (7, 3, 72, 120)
+    with torch.no_grad():
+        for i, t in enumerate(ts):
+            single = model(frames, torch.tensor(t, device=dev))[2]
+            torch.testing.assert_close(batched[i:i + 1], single, rtol=1e-4, atol=1e-5)
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_train(world, dump):
+    env = dict(os.environ, PYTHONPATH=ROOT, ARTEMIS_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    args = ["--model", "artemis", "--steps", "2", "--batch", "2", "--size", "64", "--dump", dump]
+    if world == 1:
+        cmd = [sys.executable, "-m", "artemis_amd.train", "--device", "hip:0"] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "-m",
+               "artemis_amd.train", "--backend", "gloo"] + args
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return [float(ln.split()[3]) for ln in r.stdout.splitlines() if ln.startswith("step ")]
+
+
+@pytest.mark.gpu
+def test_full_model_two_ranks_follow_the_single_process_run(tmp_path):
+    """The full-model train step (Adamax, MultiStepLR, L1, DDP) with the batch sharded over two
+    ranks (gloo, sharing the box's one GPU) follows the single-process run on the whole batch."""
+    one, two = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")
+    loss1, loss2 = _run_train(1, one), _run_train(2, two)
+    assert len(loss1) == 2 and len(loss2) == 2
+    for a, b in zip(loss1, loss2):
+        assert abs(a - b) <= 1e-4 * max(abs(a), 1.0), (loss1, loss2)
+    p1 = torch.load(one, weights_only=True)
+    p2 = torch.load(two, weights_only=True)
+    assert p1.keys() == p2.keys() and len(p1) == 380
+    # Adamax moves a parameter by about lr * sign(grad) in its first steps, so an element whose
+    # gradient is round-off around zero may go the other way in the other run (a difference of a few
+    # lr = 2e-4, whatever the tolerance of the gradients): allow a vanishing fraction of such elements
+    bad = total = 0
+    for k in p1:
+        if p1[k].dtype.is_floating_point:
+            scale = float(p1[k].abs().max())
+            diff = (p1[k] - p2[k]).abs()
+            assert float(diff.max()) <= 1e-3, k                        # never more than a few lr
+            bad += int((diff > 1e-4 * max(scale, 1e-3)).sum())
+            total += diff.numel()
+    assert bad <= 1e-4 * total, (bad, total)

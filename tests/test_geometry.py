@@ -187,7 +187,10 @@ def test_ex_arbitrary_frame_and_origin_against_oracle(dev, oracle):
             close(gw, rgw, BWD_RTOL, "grad_weight")
             close(ga, rga, BWD_RTOL, "grad_offset_y", term_size(frame, w, gout))
             close(gb, rgb, BWD_RTOL, "grad_offset_x", term_size(frame, w, gout))
-            close(gi, rgi, BWD_RTOL, "grad_input")
+            # frames of 1 to 63 texels: every element is a sum of thousands of clamped contributions,
+            # so the rounding of the sum (norm-relative, asserted) is far above 5 ulp of one term and
+            # the elementwise criterion for ~100-term sums does not apply
+            parity_close(gi, rgi, BWD_RTOL, "grad_input (tiny frames)", elementwise=False)
 
 
 @pytest.mark.gpu

@@ -30,13 +30,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("libs", nargs="+")
     ap.add_argument("--sigma", type=float, default=1.0)
+    ap.add_argument("--regime", default="", help="bench.make_offsets regime (smooth30, pan, sigma:4); default sigma:<--sigma>")
     ap.add_argument("--radius", type=int, default=-1)
     ap.add_argument("--rounds", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     libs = [(os.path.basename(p), bind(p if os.path.isabs(p) else os.path.join(ROOT, p))) for p in a.libs]
-    frames = bench.make_frames(a.batch, a.sigma, dev, 103)
+    frames = bench.make_frames(a.batch, a.sigma, dev, 103, regime=a.regime or None)
+    print(f"regime {a.regime or 'sigma:%g' % a.sigma} radius {a.radius}")
     st = torch.cuda.current_stream().cuda_stream
     H, W, B = bench.H, bench.W, a.batch
 

@@ -43,6 +43,9 @@ def main():
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if args.gin else None
     px = N * H * W
     fwd_b, bwd_b = 324.0 * px, 624.0 * px
+    # gradInput's compulsory bytes: read w, alpha, beta (300 B) + gradOutput (12), zero and write
+    # gradInput (2 x 12 B) = 336 B per pixel
+    gin_b = 336.0 * px
 
     regimes = [(f"sigma={s:g}", lambda s=s: (torch.randn(N, 25, H, W, device=dev) * s,
                                              torch.randn(N, 25, H, W, device=dev) * s))
@@ -55,12 +58,19 @@ def main():
                     (up.flip(1) + torch.randn_like(up) * 0.1).contiguous())
         regimes.append(("smooth3", smooth))
 
-        def smooth30():  # large coherent motion: low-frequency field of +-30 px, 0.3 px noise
-            lo = torch.randn(N, 1, H // 128 + 2, W // 128 + 2, device=dev) * 15
-            up = torch.nn.functional.interpolate(lo, size=(H, W), mode="bicubic").expand(N, 25, H, W)
-            return ((up + torch.randn(N, 25, H, W, device=dev) * 0.3).contiguous(),
-                    (up.flip(3) + torch.randn(N, 25, H, W, device=dev) * 0.3).contiguous())
+        def smooth30():  # large coherent motion with steep gradients (bench.make_offsets)
+            import bench
+            g = torch.Generator(device=dev).manual_seed(7)
+            return bench.make_offsets("smooth30", (N, 25, H, W), dev, g)
         regimes.append(("smooth30", smooth30))
+
+        def boundary():  # an object moving (+28, -22) px over a third of a still frame
+            oy = torch.randn(N, 25, H, W, device=dev) * 0.4
+            ox = torch.randn(N, 25, H, W, device=dev) * 0.4
+            oy[:, :, H // 4:3 * H // 4, W // 3:2 * W // 3] += 28
+            ox[:, :, H // 4:3 * H // 4, W // 3:2 * W // 3] -= 22
+            return oy, ox
+        regimes.append(("object(28,-22)", boundary))
 
         def pan():  # a camera pan: every tap displaced by (20, -35) px + N(0, 1)
             return ((torch.randn(N, 25, H, W, device=dev) + 20.0).contiguous(),
@@ -75,7 +85,7 @@ def main():
         e1.synchronize()
         return e0.elapsed_time(e1)
 
-    print(f"shape N={N} {H}x{W}; GB/s = algorithmic bytes (324 fwd / 624 bwd per pixel) / time")
+    print(f"shape N={N} {H}x{W}; GB/s = algorithmic bytes (324 fwd / 624 bwd / 336 gradInput per pixel) / time")
     for name, mk in regimes:
         oy, ox = mk()
         variants = {}
@@ -93,7 +103,7 @@ def main():
                     inp.data_ptr(), w.data_ptr(), oy.data_ptr(), ox.data_ptr(), gout.data_ptr(),
                     gin.data_ptr(), None, None, None, N, 3, H, W, 5, 1, mode, -1,
                     ws.data_ptr(), ws_bytes, st), "gin"),
-                    12.0 * px)
+                    gin_b)
         times = {k: [] for k in variants}
         for k, (fn, _) in variants.items():
             fn()
