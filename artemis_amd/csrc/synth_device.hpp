@@ -21,7 +21,7 @@
 #ifndef ARTEMIS_SYNTH_DEVICE_HPP
 #define ARTEMIS_SYNTH_DEVICE_HPP
 // Included by synth_kernels.hip (C ABI, host logic, direct kernels) and by synth_tiles.hip, which
-// is compiled once per LDS tile radius (-DSYNTH_TILE_R=2|4|8|16) so the heavy unrolled kernels
+// is compiled once per LDS tile radius (-DSYNTH_TILE_R=2|4|8|14) so the heavy unrolled kernels
 // build in parallel.  Everything but the few types and launcher declarations that cross
 // translation units lives in an anonymous namespace.
 #include <hip/hip_runtime.h>
@@ -719,26 +719,32 @@ __device__ __forceinline__ Centre unserved_centre(const float *__restrict__ ab,
     return c;
 }
 
-// The vote after a pass: all waves agree on whether to stage another window and where.
-//  1. Every wave reports how many of its pixels still have unserved taps; below kPassMinPixels
-//     for the whole tile nothing more happens (the fix-up handles a few pixels faster than a pass).
+// The vote after a pass: the waves of a window agree on whether to stage another one and where.
+//  1. Every wave reports how many of its pixels still have unserved taps; a window with fewer than
+//     kPassMinPixels of them is done (the fix-up handles a few pixels faster than a pass).
 //  2. Otherwise every wave with such pixels proposes a centre from its first one and votes for it
 //     only if it would pay: the candidate must serve at least 3/4 of the unserved taps of three
 //     other such pixels of the wave (first / last flagged row, first / last lane).  A window is
-//     staged when the waves in favour own at least half of the tile's pixels in question, at the
+//     staged when the waves in favour own at least half of the pixels in question, at the
 //     centre of the wave that owns most.  Independent large offsets (sigma = 4 px at R = 8: most
 //     pixels have a far tap or two, each in its own direction) fail that test in every wave, so
 //     they keep going straight to the fix-up and their bits do not depend on the tiling.
+// A workgroup holds NWIN windows side by side (wave column c belongs to window c * NWIN / WX);
+// barriers are workgroup-wide, so the pass loop goes on while ANY window wants another pass
+// (return value) and `mine` says whether this wave's window does (then `next` is its centre).
 // flagged[j]: ballot of row j's pixels with unserved taps (owners only).  Contains one or two
 // barriers: every wave of the workgroup calls it, active or not.  slot: WAVES x 4 floats of LDS.
-template <int R, int WAVES, int ROWS>
+template <int R, int WAVES, int ROWS, int WX, int NWIN>
 __device__ __forceinline__ bool vote_next_window(float *slot, int wv, bool active,
                                                  const unsigned long long (&flagged)[ROWS],
                                                  const int (&rowy)[ROWS], int wx0,
                                                  const float *__restrict__ ab,
                                                  const float *__restrict__ bb, size_t plane,
-                                                 const Geom &g, const Windows &w, Centre &next)
+                                                 const Geom &g, const Windows &w, Centre &next,
+                                                 bool &mine)
 {
+    constexpr int WXW = WX / NWIN;  // wave columns per window
+    const int wi = (wv % WX) / WXW;
     int cnt = 0, fy = 0, ly = 0;
     unsigned long long fb = 0, lb = 0;
     if (active) {
@@ -758,15 +764,25 @@ __device__ __forceinline__ bool vote_next_window(float *slot, int wv, bool activ
     const bool lane0 = (threadIdx.x & 63) == 0;
     if (lane0) slot[wv * 4 + 0] = (float)cnt;
     __syncthreads();
-    float total = 0.f;
+    float total[NWIN];
 #pragma unroll
-    for (int i = 0; i < WAVES; ++i) total += slot[i * 4 + 0];
+    for (int k = 0; k < NWIN; ++k) total[k] = 0.f;
+#pragma unroll
+    for (int i = 0; i < WAVES; ++i) total[(i % WX) / WXW] += slot[i * 4 + 0];
+    float total_mine = 0.f;
+    bool open_any = false;
+#pragma unroll
+    for (int k = 0; k < NWIN; ++k) {
+        open_any |= total[k] >= (float)kPassMinPixels;
+        if (k == wi) total_mine = total[k];
+    }
     next = Centre{0.f, 0.f};
-    if (__builtin_amdgcn_readfirstlane((int)(total < (float)kPassMinPixels))) return false;
+    mine = false;
+    if (!__builtin_amdgcn_readfirstlane((int)open_any)) return false;
 
     Centre cand = {0.f, 0.f};
     bool yes = false;
-    if (cnt) {  // wave-uniform
+    if (cnt && __builtin_amdgcn_readfirstlane((int)(total_mine >= (float)kPassMinPixels))) {
         cand = unserved_centre<R>(ab, bb, plane, g, fy, wx0 + __ffsll((long long)fb) - 1, w, yes);
         if (yes) {
             const int sx[3] = {wx0 + 63 - __clzll((long long)fb), wx0 + __ffsll((long long)lb) - 1,
@@ -790,20 +806,36 @@ __device__ __forceinline__ bool vote_next_window(float *slot, int wv, bool activ
         slot[wv * 4 + 3] = cand.x;
     }
     __syncthreads();
-    float in_favour = 0.f, best = 0.f;
+    float in_favour[NWIN], best[NWIN], ny[NWIN], nx[NWIN];
+#pragma unroll
+    for (int k = 0; k < NWIN; ++k) in_favour[k] = best[k] = ny[k] = nx[k] = 0.f;
 #pragma unroll
     for (int i = 0; i < WAVES; ++i) {
+        const int k = (i % WX) / WXW;
         const float c = slot[i * 4 + 1];
-        in_favour += c;
-        if (c > best) {
-            best = c;
-            next.y = slot[i * 4 + 2];
-            next.x = slot[i * 4 + 3];
+        in_favour[k] += c;
+        if (c > best[k]) {
+            best[k] = c;
+            ny[k] = slot[i * 4 + 2];
+            nx[k] = slot[i * 4 + 3];
+        }
+    }
+    bool again_any = false;
+#pragma unroll
+    for (int k = 0; k < NWIN; ++k) {
+        const bool again = total[k] >= (float)kPassMinPixels && best[k] > 0.f &&
+                           2.f * in_favour[k] >= total[k];
+        again_any |= again;
+        if (k == wi) {
+            mine = again;
+            next.y = ny[k];
+            next.x = nx[k];
         }
     }
     next.y = __builtin_amdgcn_readfirstlane(next.y);
     next.x = __builtin_amdgcn_readfirstlane(next.x);
-    return __builtin_amdgcn_readfirstlane((int)(best > 0.f && 2.f * in_favour >= total)) != 0;
+    mine = __builtin_amdgcn_readfirstlane((int)mine) != 0;
+    return __builtin_amdgcn_readfirstlane((int)again_any) != 0;
 }
 
 // Contribution of ONE tap (clamped global gathers), channels 0..2.
@@ -823,25 +855,27 @@ __device__ __forceinline__ Float3 fwd_tap_global(FP ip, const Geom &g, float wv,
     return o;
 }
 
-// Sum over the out-of-tile taps of pixel (y, xs), computed by the whole wave (lane l < 25 owns
-// tap l).  wb/ab/bb: tap 0 of the sample's planes; ip: the sample's frame.  Result in every lane.
-template <int R, class FP>
+// Which taps of a pixel are still unserved is a 25-bit mask kept by the pixel's lane (bit t = tap t),
+// set in the first pass over the taps and cleared by later windows that serve them.
+constexpr int kMaskMaxTaps = 4;  // at most this many unserved taps per pixel: every lane fixes its own
+
+// Sum over the unserved taps (`mask`, wave-uniform) of pixel (y, xs), computed by the whole wave
+// (lane l < 25 owns tap l).  wb/ab/bb: tap 0 of the sample's planes; ip: the sample's frame.
+// Result in every lane.
+template <class FP>
 __device__ __forceinline__ Float3 fwd_outside_coop(FP ip,
                                                    const float *__restrict__ wb,
                                                    const float *__restrict__ ab,
-                                                   const float *__restrict__ bb, const Geom &g, const Windows &win, int y,
-                                                   int xs)
+                                                   const float *__restrict__ bb, const Geom &g,
+                                                   unsigned mask, int y, int xs)
 {
     const int l = threadIdx.x & 63;
     const size_t plane = (size_t)g.H * g.W;
     Float3 c = {0.f, 0.f, 0.f};
-    if (l < 25) {
+    if (l < 25 && ((mask >> l) & 1u)) {
         const size_t o = (size_t)l * plane + (size_t)y * g.W + xs;
-        const float a = ab[o], b = bb[o];
-        if (!tap_in_windows<R>(a, b, win)) {
-            const int r = l / 5, s = l - 5 * r;
-            c = fwd_tap_global(ip, g, wb[o], a, b, y + g.oy0 + r, xs + g.ox0 + s);
-        }
+        const int r = l / 5, s = l - 5 * r;
+        c = fwd_tap_global(ip, g, wb[o], ab[o], bb[o], y + g.oy0 + r, xs + g.ox0 + s);
     }
     c.x = wave_sum(c.x);
     c.y = wave_sum(c.y);
@@ -849,13 +883,14 @@ __device__ __forceinline__ Float3 fwd_outside_coop(FP ip,
     return c;
 }
 
-// The same sum by one lane for its own pixel (used when many lanes of the wave are flagged).
-template <int R, class FP>
+// The same sum by one lane for its own pixel (used when many lanes of the wave are flagged and
+// some have many unserved taps): a tap row's loads are issued together.
+template <class FP>
 __device__ __forceinline__ Float3 fwd_outside_lane(FP ip,
                                                    const float *__restrict__ wp,
                                                    const float *__restrict__ ap,
-                                                   const float *__restrict__ bp, const Geom &g, const Windows &win, int y,
-                                                   int x)
+                                                   const float *__restrict__ bp, const Geom &g,
+                                                   unsigned mask, int y, int x)
 {
     const size_t plane = (size_t)g.H * g.W;
     Float3 c = {0.f, 0.f, 0.f};
@@ -864,9 +899,8 @@ __device__ __forceinline__ Float3 fwd_outside_lane(FP ip,
 #pragma unroll
         for (int s = 0; s < 5; ++s) {
             const size_t o = (size_t)(r * 5 + s) * plane;
-            const float a = ap[o], b = bp[o];
-            if (!tap_in_windows<R>(a, b, win)) {
-                const Float3 t = fwd_tap_global(ip, g, wp[o], a, b, y + g.oy0 + r, x + g.ox0 + s);
+            if ((mask >> (r * 5 + s)) & 1u) {
+                const Float3 t = fwd_tap_global(ip, g, wp[o], ap[o], bp[o], y + g.oy0 + r, x + g.ox0 + s);
                 c.x += t.x;
                 c.y += t.y;
                 c.z += t.z;
@@ -874,6 +908,59 @@ __device__ __forceinline__ Float3 fwd_outside_lane(FP ip,
         }
     }
     return c;
+}
+
+// ... and by every lane for its own pixels one tap per step, lowest unserved tap first, all lanes
+// of the wave in parallel and the wave's NR rows together: two memory round trips per step
+// whatever the number of pixels, where the whole-wave form pays two per PIXEL.  For rows whose
+// pixels have few unserved taps each (independent offsets a little beyond the radius: sigma = 4 px
+// at R = 14 leaves one such tap in 1 % of the pixels, i.e. in every other wave row).
+// mask[j] = 0 for a row that does not take part.  wp/ap/bp: tap 0 at this lane's column x of row 0
+// of the planes (row j at + roff[j]).
+template <int NR, class FP>
+__device__ __forceinline__ void fwd_outside_steps(FP ip, const float *__restrict__ wp,
+                                                  const float *__restrict__ ap,
+                                                  const float *__restrict__ bp, const Geom &g,
+                                                  unsigned (&mask)[NR], const size_t (&roff)[NR],
+                                                  const int (&rowy)[NR], int x, float (&acc0)[NR],
+                                                  float (&acc1)[NR], float (&acc2)[NR])
+{
+    const size_t plane = (size_t)g.H * g.W;
+    for (;;) {
+        unsigned any = 0;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) any |= mask[j];
+        if (!__ballot(any != 0)) break;  // wave-uniform
+        float wv[NR], a[NR], b[NR];
+        int t[NR];
+        bool on[NR];
+        unsigned long long rowon[NR];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {  // the operands of every row's next tap: one round of loads
+            on[j] = mask[j] != 0;
+            rowon[j] = __ballot(on[j]);  // rows without work issue nothing (wave-uniform)
+            t[j] = on[j] ? __ffs((int)mask[j]) - 1 : 0;
+            mask[j] &= mask[j] - (on[j] ? 1u : 0u);
+            wv[j] = a[j] = b[j] = 0.f;
+            if (rowon[j]) {
+                const size_t o = (size_t)t[j] * plane + roff[j];
+                wv[j] = wp[o];
+                a[j] = ap[o];
+                b[j] = bp[o];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {  // their gathers
+            if (rowon[j]) {
+                const int r = (t[j] * 13) >> 6, s = t[j] - 5 * r;  // t / 5 for t < 25
+                const Float3 v = fwd_tap_global(ip, g, wv[j], a[j], b[j], rowy[j] + g.oy0 + r,
+                                                x + g.ox0 + s);
+                acc0[j] += on[j] ? v.x : 0.f;
+                acc1[j] += on[j] ? v.y : 0.f;
+                acc2[j] += on[j] ? v.z : 0.f;
+            }
+        }
+    }
 }
 
 // One tap of the fused backward through clamped global gathers; o = element offset of
@@ -905,43 +992,40 @@ __device__ __forceinline__ float bwd_tap_global(FP ip, const Geom &g, float wv,
     return wv * gwr;
 }
 
-// Out-of-tile taps of pixel (y, xs) recomputed and stored by the whole wave.
+// Unserved taps (`mask`, wave-uniform) of pixel (y, xs) recomputed and stored by the whole wave.
 // gn: the sample's gradOutput planes; gwn/goyn/goxn: tap 0 of the sample's gradient planes.
 // Returns (in every lane) the sum over those taps of w * unscaled gradWeight.
-template <int R, class FP>
+template <class FP>
 __device__ __forceinline__ float bwd_outside_coop(FP ip,
                                                   const float *__restrict__ wb,
                                                   const float *__restrict__ ab,
                                                   const float *__restrict__ bb,
                                                   const float *__restrict__ gn, float *__restrict__ gwn,
                                                   float *__restrict__ goyn, float *__restrict__ goxn,
-                                                  const Geom &g, const Windows &win, int y, int xs, float scale,
+                                                  const Geom &g, unsigned mask, int y, int xs, float scale,
                                                   bool want_sum)
 {
     const int l = threadIdx.x & 63;
     float c = 0.f;
-    if (l < 25) {
+    if (l < 25 && ((mask >> l) & 1u)) {
         const size_t plane = (size_t)g.H * g.W;
         const size_t pix = (size_t)y * g.W + xs;
         const size_t o = (size_t)l * plane + pix;
-        const float a = ab[o], b = bb[o];
-        if (!tap_in_windows<R>(a, b, win)) {
-            const int r = l / 5, s = l - 5 * r;
-            c = bwd_tap_global(ip, g, wb[o], a, b, gn[pix], gn[plane + pix], gn[2 * plane + pix],
-                               y + g.oy0 + r, xs + g.ox0 + s, gwn, goyn, goxn, o, scale);
-        }
+        const int r = l / 5, s = l - 5 * r;
+        c = bwd_tap_global(ip, g, wb[o], ab[o], bb[o], gn[pix], gn[plane + pix], gn[2 * plane + pix],
+                           y + g.oy0 + r, xs + g.ox0 + s, gwn, goyn, goxn, o, scale);
     }
     return want_sum ? wave_sum(c) : 0.f;
 }
 
-template <int R, class FP>
+template <class FP>
 __device__ __forceinline__ float bwd_outside_lane(FP ip,
                                                   const float *__restrict__ wb,
                                                   const float *__restrict__ ab,
                                                   const float *__restrict__ bb, float d0, float d1,
                                                   float d2, float *__restrict__ gwn,
                                                   float *__restrict__ goyn, float *__restrict__ goxn,
-                                                  const Geom &g, const Windows &win, int y, int x, float scale)
+                                                  const Geom &g, unsigned mask, int y, int x, float scale)
 {
     const size_t plane = (size_t)g.H * g.W;
     const size_t pix = (size_t)y * g.W + x;
@@ -951,13 +1035,59 @@ __device__ __forceinline__ float bwd_outside_lane(FP ip,
 #pragma unroll
         for (int s = 0; s < 5; ++s) {
             const size_t o = (size_t)(r * 5 + s) * plane + pix;
-            const float a = ab[o], b = bb[o];
-            if (!tap_in_windows<R>(a, b, win))
-                c += bwd_tap_global(ip, g, wb[o], a, b, d0, d1, d2, y + g.oy0 + r, x + g.ox0 + s, gwn,
-                                    goyn, goxn, o, scale);
+            if ((mask >> (r * 5 + s)) & 1u)
+                c += bwd_tap_global(ip, g, wb[o], ab[o], bb[o], d0, d1, d2, y + g.oy0 + r, x + g.ox0 + s,
+                                    gwn, goyn, goxn, o, scale);
         }
     }
     return c;
+}
+
+// one tap per step, all lanes in parallel, NR rows together (see fwd_outside_steps); gocc[j] gets
+// the sum over row j's taps of w * unscaled gradWeight
+template <int NR, class FP>
+__device__ __forceinline__ void bwd_outside_steps(FP ip, const float *__restrict__ wb,
+                                                  const float *__restrict__ ab,
+                                                  const float *__restrict__ bb,
+                                                  const float (&d)[NR][3], float *__restrict__ gwn,
+                                                  float *__restrict__ goyn, float *__restrict__ goxn,
+                                                  const Geom &g, unsigned (&mask)[NR],
+                                                  const size_t (&roff)[NR], const int (&rowy)[NR], int x,
+                                                  const float (&scale)[NR], float (&gocc)[NR])
+{
+    const size_t plane = (size_t)g.H * g.W;
+    for (;;) {
+        unsigned any = 0;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) any |= mask[j];
+        if (!__ballot(any != 0)) break;  // wave-uniform
+        float wv[NR], a[NR], b[NR];
+        int t[NR];
+        bool on[NR];
+        size_t o[NR];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            on[j] = mask[j] != 0;
+            t[j] = on[j] ? __ffs((int)mask[j]) - 1 : 0;
+            mask[j] &= mask[j] - (on[j] ? 1u : 0u);
+            o[j] = (size_t)t[j] * plane + roff[j] + x;
+            wv[j] = a[j] = b[j] = 0.f;
+            if (__ballot(on[j])) {  // rows without work issue nothing (wave-uniform)
+                wv[j] = wb[o[j]];
+                a[j] = ab[o[j]];
+                b[j] = bb[o[j]];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            if (on[j]) {  // (stores: a lane without a tap must not write)
+                const int r = (t[j] * 13) >> 6, s = t[j] - 5 * r;  // t / 5 for t < 25
+                gocc[j] += bwd_tap_global(ip, g, wv[j], a[j], b[j], d[j][0], d[j][1], d[j][2],
+                                          rowy[j] + g.oy0 + r, x + g.ox0 + s, gwn, goyn, goxn, o[j],
+                                          scale[j]);
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -998,13 +1128,15 @@ __device__ __forceinline__ void load_tap_col(TapCol<ROWS> &t, const float *__res
     }
 }
 
-// Stage the clamped frame tile.  Texels are fetched in batches of kFillBatch per lane with all of
-// a batch's loads issued before the first LDS write: left to itself hipcc waits vmcnt(0) after
-// every texel, which serialises ~14 L2 round trips (~10 us) at the head of every workgroup.
+// Stage the clamped frame window.  Texels are fetched in batches with all of a batch's loads issued
+// before the first LDS write: left to itself hipcc waits vmcnt(0) after every texel, which
+// serialises ~14 L2 round trips (~10 us) at the head of every workgroup.  The batch size balances
+// the rounds: as few rounds as batches of at most kFillBatchMax allow, all of about the same size
+// (R = 8: one round of 13 texels per lane; R = 14: two of 10).
 #ifndef SYNTH_FILL_BATCH
-#define SYNTH_FILL_BATCH 11
+#define SYNTH_FILL_BATCH 13
 #endif
-constexpr int kFillBatch = SYNTH_FILL_BATCH;
+constexpr int kFillBatchMax = SYNTH_FILL_BATCH;
 
 template <int R, int TH, int THREADS, int TW, class FP>
 __device__ __forceinline__ void fill_tile_n(f32x4 *tile, FP ip, const Geom &g,
@@ -1012,12 +1144,14 @@ __device__ __forceinline__ void fill_tile_n(f32x4 *tile, FP ip, const Geom &g,
 {
     constexpr int LW = TileShape<R, TH, TW>::LW, LH = TileShape<R, TH, TW>::LH;
     constexpr int N = LH * LW;
+    constexpr int ROUNDS = (N + THREADS * kFillBatchMax - 1) / (THREADS * kFillBatchMax);
+    constexpr int BATCH = (N + THREADS * ROUNDS - 1) / (THREADS * ROUNDS);
     const int iplane = g.Hin * g.Win;
 #pragma unroll 1
-    for (int base = tid; base < N; base += THREADS * kFillBatch) {
-        float c0[kFillBatch], c1[kFillBatch], c2[kFillBatch];
+    for (int base = tid; base < N; base += THREADS * BATCH) {
+        float c0[BATCH], c1[BATCH], c2[BATCH];
 #pragma unroll
-        for (int u = 0; u < kFillBatch; ++u) {
+        for (int u = 0; u < BATCH; ++u) {
             const int i = min(base + u * THREADS, N - 1);  // tail lanes re-fetch the last texel
             const int ly = i / LW, lx = i - ly * LW;
             const int gy = clampi(gy0 + ly, 0, g.Hin - 1), gx = clampi(gx0 + lx, 0, g.Win - 1);
@@ -1027,7 +1161,7 @@ __device__ __forceinline__ void fill_tile_n(f32x4 *tile, FP ip, const Geom &g,
             c2[u] = ip[2 * (size_t)iplane + o];
         }
 #pragma unroll
-        for (int u = 0; u < kFillBatch; ++u) {
+        for (int u = 0; u < BATCH; ++u) {
             const int i = min(base + u * THREADS, N - 1);
             tile[i] = f32x4{c0[u], c1[u], c2[u], 0.f};
         }
@@ -1090,28 +1224,35 @@ __device__ __forceinline__ int in_branch(int v)
 }
 
 
-template <int R, int WAVES, int ROWS, int OCC, bool HEAD, class FT, int WX = 1>
+template <int R, int WAVES, int ROWS, int OCC, bool HEAD, class FT, int WX = 1, int NWIN = 1>
 __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
     const FT *__restrict__ in, const float *__restrict__ w, const float *__restrict__ oy,
     const float *__restrict__ ox, float *__restrict__ out, Geom g, HeadArgs ha)
 {
     // WX waves side by side: the tile is 64 * WX pixels wide and (WAVES / WX) * ROWS rows high
     constexpr int TW = 64 * WX, WY = WAVES / WX, TH = WY * ROWS;
-    constexpr int LW = TileShape<R, TH, TW>::LW, LH = TileShape<R, TH, TW>::LH;
-    __shared__ f32x4 tile[LH * LW];
+    // NWIN staged windows side by side, each serving SW = TW / NWIN tile columns (WXW wave columns)
+    // with its own centres: the wide tile keeps its 512-byte plane rows, while the motion only has
+    // to be coherent over SW pixels for a window to serve it
+    constexpr int SW = TW / NWIN, WXW = WX / NWIN;
+    constexpr int LW = TileShape<R, TH, SW>::LW, LH = TileShape<R, TH, SW>::LH;
+    static_assert(WX % NWIN == 0, "wave columns must split evenly over the windows");
+    __shared__ f32x4 tile_all[NWIN * LH * LW];
     __shared__ float vote_slot[WAVES * 4];
-    const lds_f32x4 *ltile = (const lds_f32x4 *)tile;
     int tx0, ty0;
     if (!tile_origin<TH, TW>(g, tx0, ty0)) return;
     const int n = blockIdx.z;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
     const int wy = wv / WX, wx0 = tx0 + (wv % WX) * 64;  // the wave's first row slot and column
-    const int tid = wv * 64 + threadIdx.x;
+    const int wi = (wv % WX) / WXW, sx0 = tx0 + wi * SW;  // its window and that window's first column
+    f32x4 *tile = tile_all + wi * (LH * LW);
+    const lds_f32x4 *ltile = (const lds_f32x4 *)tile;
+    const int tid = (wy * WXW + (wv % WX) % WXW) * 64 + threadIdx.x;  // thread index among the window's
     const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
     // A lane past the right edge acts as the last image column (same operands, same arithmetic,
     // same stores as that column's owner), like the rows below: no lane ever retires on its own,
     // so wave-wide operations in the fix-up see all 64 lanes.
-    const int x = min(wx0 + (int)threadIdx.x, g.W - 1), px = x - tx0;
+    const int x = min(wx0 + (int)threadIdx.x, g.W - 1), px = x - sx0;
     const bool owner = wx0 + (int)threadIdx.x == x;   // not a right-edge duplicate
     // wave-uniform; a wave without pixels only takes part in the tile fills, barriers and votes
     const bool active = ty0 + wy < g.H && wx0 < g.W;
@@ -1160,21 +1301,19 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
         }
 
         float acc0[ROWS], acc1[ROWS], acc2[ROWS];
-        float mabs[ROWS];  // per row: the largest (over taps) of the smallest (over windows) reach
+        unsigned fmask[ROWS];  // per row: bit t = tap t of this lane's pixel is served by no window yet
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) {
             acc0[j] = acc1[j] = acc2[j] = 0.f;
-            mabs[j] = 0.f;
+            fmask[j] = 0u;
         }
 
         // One pass over the 25 taps with the window centred at `ctr`.  FIRST: the window is the
         // tile's first one (every tap it serves is added); otherwise only taps that it serves and
         // no earlier window (`prev`) did.
-        auto run_taps = [&](auto first_tag, const Centre ctr, const Windows &prev) {
+        auto run_taps = [&](auto first_tag, const Centre ctr) {
             constexpr bool FIRST = decltype(first_tag)::value != 0;
             const int cbase = (((int)ctr.y) * LW + (int)ctr.x) * 16;  // the window's shift
-#pragma unroll
-            for (int j = 0; j < ROWS; ++j) mabs[j] = 0.f;
             static_for<0, 25>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
                 constexpr int r = t / 5, s = t % 5;
@@ -1187,16 +1326,14 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
                     const int ia = (int)a, ib = (int)b;
                     const float fa = a - (float)ia, fb = b - (float)ib;
                     const float reach = fmaxf(fabsf((float)ia - ctr.y), fabsf((float)ib - ctr.x));
-                    bool near;
+                    bool near = reach <= (float)R;
                     if constexpr (FIRST) {
-                        mabs[j] = fmaxf(mabs[j], reach);
-                        near = reach <= (float)R;
+                        fmask[j] |= near ? 0u : 1u << t;
                     } else {
-                        const float before = windows_reach(a, b, prev);
-                        mabs[j] = fmaxf(mabs[j], fminf(reach, before));
-                        near = reach <= (float)R && !(before <= (float)R);
+                        near = near && ((fmask[j] >> t) & 1u);
+                        fmask[j] &= near ? ~(1u << t) : ~0u;
                     }
-                    const Corners q = tile_corners_at<R, TH, r * LW + s, TW>(ltile, ia, ib, rowbase[j] - cbase);
+                    const Corners q = tile_corners_at<R, TH, r * LW + s, SW>(ltile, ia, ib, rowbase[j] - cbase);
                     const float ga = 1.f - fa, gb = 1.f - fb;
                     const float c00 = ga * gb, c10 = fa * gb, c01 = ga * fb, c11 = fa * fb;
                     // A tap this window does not serve is added elsewhere.  Its term is dropped by a
@@ -1213,7 +1350,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
                     // chain-free FMAs to the end of the unrolled block, keeping every LDS result of
                     // the pixel live (512 VGPRs or spills).  The sched_barrier bounds the LDS results
                     // in flight to kRowGroup rows (16 VGPRs each).
-                    asm volatile("" : "+v"(acc0[j]), "+v"(acc1[j]), "+v"(acc2[j]), "+v"(mabs[j]));
+                    asm volatile("" : "+v"(acc0[j]), "+v"(acc1[j]), "+v"(acc2[j]), "+v"(fmask[j]));
                     if (j % kRowGroup == kRowGroup - 1) __builtin_amdgcn_sched_barrier(0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -1221,9 +1358,29 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
             });
         };
 
-        Windows win = one_window(tile_centre<R>(ab, bb, pl, g, tx0, ty0, TH, TW));
+        // Rows whose pixels have at most kMaskMaxTaps unserved taps each: every lane fixes its own
+        // pixels through clamped global gathers, all such rows together (fwd_outside_steps), and the
+        // rows are done (mask cleared).  Called right after the first pass -- before the vote's
+        // barrier, so that the gathers of one wave overlap the tap loops of the others, and such
+        // pixels do not count in the vote -- and again after the last pass.
+        auto fix_few = [&]() {
+            unsigned sm[ROWS];
+            bool some = false;
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) {
+                const bool few = __ballot(fmask[j] != 0u) && !__ballot(__popc(fmask[j]) > kMaskMaxTaps);
+                sm[j] = few ? fmask[j] : 0u;  // (few is wave-uniform)
+                if (few) fmask[j] = 0u;
+                some |= few;
+            }
+            if (some)  // wave-uniform, rare
+                fwd_outside_steps<ROWS>(ip, wb + x, ab + x, bb + x, g, sm, rf, rowy, x, acc0, acc1, acc2);
+        };
+
+        Windows win = one_window(tile_centre<R>(ab, bb, pl, g, sx0, ty0, TH, SW));
         Centre ctr = win.c0;
         unsigned long long flagged[ROWS];
+        bool mine = true;  // this wave's window is (re)staged in the coming pass
 #pragma unroll 1
         for (int p = 0;; ++p) {
             // (the per-tap addresses are invariant in this loop too: keep them from being hoisted
@@ -1234,57 +1391,63 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
             // every wave is done with the previous window (frame f - 1's last one; within a frame
             // the vote's barrier has already seen to that)
             if (HEAD && f > 0 && p == 0) __syncthreads();
-            fill_tile_n<R, TH, 64 * WAVES, TW>(tile, ip, g, ty0 + g.oy0 - R + (int)ctr.y,
-                                               tx0 + g.ox0 - R + (int)ctr.x, tid);
+            if (mine)
+                fill_tile_n<R, TH, 64 * (WAVES / NWIN), SW>(tile, ip, g, ty0 + g.oy0 - R + (int)ctr.y,
+                                                            sx0 + g.ox0 - R + (int)ctr.x, tid);
             __syncthreads();
             if (p == 0) {
-                if (active) run_taps(IntTag<1>{}, ctr, win);
+                if (active) {
+                    run_taps(IntTag<1>{}, ctr);
+                    fix_few();
+                }
             } else {
                 bool any = false;
 #pragma unroll
                 for (int j = 0; j < ROWS; ++j) any |= flagged[j] != 0;
-                if (active && any) {  // wave-uniform
-                    Windows prev = win;  // the windows before this one
-                    if (p == 1) prev.c1 = Centre{kNoCentre, kNoCentre};
-                    else prev.c2 = Centre{kNoCentre, kNoCentre};
+                if (mine && active && any) {  // wave-uniform
                     load_tap_col<ROWS>(cur, wb, ab, bb, pl, 0, rf, (unsigned)x);
-                    run_taps(IntTag<0>{}, ctr, prev);
+                    run_taps(IntTag<0>{}, ctr);
                 }
             }
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
-                flagged[j] = active ? __ballot(!(mabs[j] <= (float)R) && owner) : 0ull;
+                flagged[j] = active ? __ballot(fmask[j] != 0u && owner) : 0ull;
             if (p + 1 == kMaxPasses) break;
             Centre next;
-            if (!vote_next_window<R, WAVES, ROWS>(vote_slot, wv, active, flagged, rowy, wx0, ab, bb, pl, g,
-                                                  win, next))
+            if (!vote_next_window<R, WAVES, ROWS, WX, NWIN>(vote_slot, wv, active, flagged, rowy, wx0, ab,
+                                                            bb, pl, g, win, next, mine))
                 break;
-            if (p == 0) win.c1 = next;
-            else win.c2 = next;
-            ctr = next;
+            if (mine) {  // (else another window of the workgroup goes on: only its barriers matter here)
+                if (p == 0) win.c1 = next;
+                else win.c2 = next;
+                ctr = next;
+            }
         }
         if (!active) continue;  // (it has taken part in this frame's fills, barriers and votes)
 
+        // Taps that no window served are added through clamped global gathers.  Rows whose pixels
+        // have few such taps each went first (fix_few, right after the first pass and again here) ...
+        fix_few();
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) {
-            // taps that no window served are added through clamped global gathers
-            unsigned long long todo = flagged[j];
-            const bool flag = !(mabs[j] <= (float)R);
+            // ... the others pixel by pixel by the whole wave, or lane by lane when there are many
+            unsigned long long todo = __ballot(fmask[j] != 0u && owner);
             if (todo) {  // wave-uniform, rare
+                const size_t o = rf[j] + x;
                 if (__popcll(todo) <= kCoopMaxPixels) {
                     while (todo) {
                         const int b = __ffsll((long long)todo) - 1;
                         todo &= todo - 1;
-                        const Float3 c = fwd_outside_coop<R>(ip, wb, ab, bb, g, win, rowy[j], wx0 + b);
+                        const Float3 c = fwd_outside_coop(ip, wb, ab, bb, g, (unsigned)__shfl((int)fmask[j], b),
+                                                          rowy[j], wx0 + b);
                         if (x == wx0 + b) {  // the owner and its right-edge duplicates
                             acc0[j] += c.x;
                             acc1[j] += c.y;
                             acc2[j] += c.z;
                         }
                     }
-                } else if (flag) {
-                    const size_t o = rf[j] + x;
-                    const Float3 c = fwd_outside_lane<R>(ip, wb + o, ab + o, bb + o, g, win, rowy[j], x);
+                } else if (fmask[j]) {
+                    const Float3 c = fwd_outside_lane(ip, wb + o, ab + o, bb + o, g, fmask[j], rowy[j], x);
                     acc0[j] += c.x;
                     acc1[j] += c.y;
                     acc2[j] += c.z;
@@ -1317,7 +1480,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
 // out = sum_f occ_f * S_f; per frame the kernel forms the unscaled tap gradients from it, stores
 // them times occ_f into slice [n, f] of the 5-D gradient tensors in place, and accumulates
 // gocc[n, f] = sum_c gradOutput_c * S_f,c = sum_t w_t * (unscaled gradWeight_t) in registers.
-template <int R, int WAVES, int ROWS, int OCC, bool ALL, bool HEAD, class FT, int WX = 1>
+template <int R, int WAVES, int ROWS, int OCC, bool ALL, bool HEAD, class FT, int WX = 1, int NWIN = 1>
 __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
     const FT *__restrict__ in, const float *__restrict__ w, const float *__restrict__ oy,
     const float *__restrict__ ox, const float *__restrict__ gout, float *__restrict__ gw,
@@ -1325,19 +1488,26 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
 {
     // WX waves side by side: the tile is 64 * WX pixels wide and (WAVES / WX) * ROWS rows high
     constexpr int TW = 64 * WX, WY = WAVES / WX, TH = WY * ROWS;
-    constexpr int LW = TileShape<R, TH, TW>::LW, LH = TileShape<R, TH, TW>::LH;
-    __shared__ f32x4 tile[LH * LW];
+    // NWIN staged windows side by side, each serving SW = TW / NWIN tile columns (WXW wave columns)
+    // with its own centres: the wide tile keeps its 512-byte plane rows, while the motion only has
+    // to be coherent over SW pixels for a window to serve it
+    constexpr int SW = TW / NWIN, WXW = WX / NWIN;
+    constexpr int LW = TileShape<R, TH, SW>::LW, LH = TileShape<R, TH, SW>::LH;
+    static_assert(WX % NWIN == 0, "wave columns must split evenly over the windows");
+    __shared__ f32x4 tile_all[NWIN * LH * LW];
     __shared__ float vote_slot[WAVES * 4];
-    const lds_f32x4 *ltile = (const lds_f32x4 *)tile;
     int tx0, ty0;
     if (!tile_origin<TH, TW>(g, tx0, ty0)) return;
     const int n = blockIdx.z;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
     const int wy = wv / WX, wx0 = tx0 + (wv % WX) * 64;  // the wave's first row slot and column
-    const int tid = wv * 64 + threadIdx.x;
+    const int wi = (wv % WX) / WXW, sx0 = tx0 + wi * SW;  // its window and that window's first column
+    f32x4 *tile = tile_all + wi * (LH * LW);
+    const lds_f32x4 *ltile = (const lds_f32x4 *)tile;
+    const int tid = (wy * WXW + (wv % WX) % WXW) * 64 + threadIdx.x;  // thread index among the window's
     const size_t plane = (size_t)g.H * g.W, iplane = (size_t)g.Hin * g.Win;
     // lanes past the right edge duplicate the last image column (see forward)
-    const int x = min(wx0 + (int)threadIdx.x, g.W - 1), px = x - tx0;
+    const int x = min(wx0 + (int)threadIdx.x, g.W - 1), px = x - sx0;
     const bool owner = wx0 + (int)threadIdx.x == x;
     const bool active = ty0 + wy < g.H && wx0 < g.W;  // wave-uniform (see forward)
 
@@ -1381,19 +1551,17 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
             }
         }
 
-        float mabs[ROWS];
+        unsigned fmask[ROWS];  // bit t = tap t of this lane's pixel is served by no window yet
 #pragma unroll
-        for (int j = 0; j < ROWS; ++j) mabs[j] = 0.f;
+        for (int j = 0; j < ROWS; ++j) fmask[j] = 0u;
 
         // One pass over the 25 taps with the window centred at `ctr` (see forward).  FIRST: all
         // three gradients of every tap are stored (those of a tap the window does not serve are
         // overwritten later -- same lane or same wave, program order); otherwise only the taps
         // that this window serves and no earlier one did are stored.
-        auto run_taps = [&](auto first_tag, const Centre ctr, const Windows &prev) {
+        auto run_taps = [&](auto first_tag, const Centre ctr) {
             constexpr bool FIRST = decltype(first_tag)::value != 0;
             const int cbase = (((int)ctr.y) * LW + (int)ctr.x) * 16;  // the window's shift
-#pragma unroll
-            for (int j = 0; j < ROWS; ++j) mabs[j] = 0.f;
             static_for<0, 25>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
                 constexpr int r = t / 5, s = t % 5;
@@ -1406,16 +1574,14 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
                     const int ia = (int)a, ib = (int)b;
                     const float fa = a - (float)ia, fb = b - (float)ib;
                     const float reach = fmaxf(fabsf((float)ia - ctr.y), fabsf((float)ib - ctr.x));
-                    bool near;
+                    bool near = reach <= (float)R;
                     if constexpr (FIRST) {
-                        mabs[j] = fmaxf(mabs[j], reach);
-                        near = reach <= (float)R;
+                        fmask[j] |= near ? 0u : 1u << t;
                     } else {
-                        const float before = windows_reach(a, b, prev);
-                        mabs[j] = fmaxf(mabs[j], fminf(reach, before));
-                        near = reach <= (float)R && !(before <= (float)R);
+                        near = near && ((fmask[j] >> t) & 1u);
+                        fmask[j] &= near ? ~(1u << t) : ~0u;
                     }
-                    const Corners q = tile_corners_at<R, TH, r * LW + s, TW>(ltile, ia, ib, rowbase[j] - cbase);
+                    const Corners q = tile_corners_at<R, TH, r * LW + s, SW>(ltile, ia, ib, rowbase[j] - cbase);
                     const float pbl = d[j][0] * q.bl.x + d[j][1] * q.bl.y + d[j][2] * q.bl.z;
                     const float ptl = d[j][0] * q.tl.x + d[j][1] * q.tl.y + d[j][2] * q.tl.z;
                     const float pbr = d[j][0] * q.br.x + d[j][1] * q.br.y + d[j][2] * q.br.z;
@@ -1443,7 +1609,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
                         if (ALL || goy) st_stream(goy + o + (unsigned)x, gar);
                         if (ALL || gox) st_stream(gox + o + (unsigned)x, gbr);
                     }
-                    asm volatile("" : "+v"(mabs[j]));
+                    asm volatile("" : "+v"(fmask[j]));
                     if (j % kRowGroup == kRowGroup - 1) __builtin_amdgcn_sched_barrier(0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -1451,17 +1617,57 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
             });
         };
 
-        Windows win = one_window(tile_centre<R>(ab, bb, pl, g, tx0, ty0, TH, TW));
+        // Rows whose pixels have at most kMaskMaxTaps unserved taps each (see forward): every lane
+        // fixes its own pixels, kStepRows rows together; overwrites what the first pass stored for
+        // those taps (same lane: program order).
+        float *gwn = gw ? gw + nb : nullptr, *goyn = goy ? goy + nb : nullptr,
+              *goxn = gox ? gox + nb : nullptr;
+        auto fix_few = [&]() {
+            constexpr int kStepRows = ROWS < 4 ? ROWS : 4;
+#pragma unroll
+            for (int j0 = 0; j0 < ROWS; j0 += kStepRows) {
+                unsigned sm[kStepRows];
+                size_t sr[kStepRows];
+                int sy[kStepRows];
+                float sd[kStepRows][3], ss[kStepRows], sg[kStepRows];
+                bool some = false;
+#pragma unroll
+                for (int i = 0; i < kStepRows; ++i) {
+                    const int j = j0 + i;
+                    const bool few = __ballot(fmask[j] != 0u) && !__ballot(__popc(fmask[j]) > kMaskMaxTaps);
+                    sm[i] = few ? fmask[j] : 0u;  // (few is wave-uniform)
+                    if (few) fmask[j] = 0u;
+                    some |= few;
+                    sr[i] = rf[j];
+                    sy[i] = rowy[j];
+                    sd[i][0] = d[j][0], sd[i][1] = d[j][1], sd[i][2] = d[j][2];
+                    ss[i] = HEAD ? occv[j] : 1.f;
+                    sg[i] = 0.f;
+                }
+                if (some) {  // wave-uniform, rare
+                    bwd_outside_steps<kStepRows>(ip, wb, ab, bb, sd, gwn, goyn, goxn, g, sm, sr, sy,
+                                                 HEAD ? in_branch(x) : x, ss, sg);
+                    if constexpr (HEAD) {
+#pragma unroll
+                        for (int i = 0; i < kStepRows; ++i) gocc[j0 + i] += sg[i];
+                    }
+                }
+            }
+        };
+
+        Windows win = one_window(tile_centre<R>(ab, bb, pl, g, sx0, ty0, TH, SW));
         Centre ctr = win.c0;
         unsigned long long flagged[ROWS];
+        bool mine = true;  // this wave's window is (re)staged in the coming pass
 #pragma unroll 1
         for (int p = 0;; ++p) {
             pl = per_frame(pl);  // (see forward)
 #pragma unroll
             for (int j = 0; j < ROWS; ++j) rf[j] = per_frame(rf[j]);
             if (HEAD && f > 0 && p == 0) __syncthreads();  // every wave is done with the previous window
-            fill_tile_n<R, TH, 64 * WAVES, TW>(tile, ip, g, ty0 + g.oy0 - R + (int)ctr.y,
-                                               tx0 + g.ox0 - R + (int)ctr.x, tid);
+            if (mine)
+                fill_tile_n<R, TH, 64 * (WAVES / NWIN), SW>(tile, ip, g, ty0 + g.oy0 - R + (int)ctr.y,
+                                                            sx0 + g.ox0 - R + (int)ctr.x, tid);
             __syncthreads();
             if (p == 0) {
                 if (active) {
@@ -1473,57 +1679,58 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
                             d[j][2] = ld_stream(gb_ + 2 * pl + rf[j] + (unsigned)x);
                         }
                     }
-                    run_taps(IntTag<1>{}, ctr, win);
+                    run_taps(IntTag<1>{}, ctr);
+                    fix_few();
                 }
             } else {
                 bool any = false;
 #pragma unroll
                 for (int j = 0; j < ROWS; ++j) any |= flagged[j] != 0;
-                if (active && any) {  // wave-uniform
-                    Windows prev = win;  // the windows before this one
-                    if (p == 1) prev.c1 = Centre{kNoCentre, kNoCentre};
-                    else prev.c2 = Centre{kNoCentre, kNoCentre};
+                if (mine && active && any) {  // wave-uniform
                     load_tap_col<ROWS>(cur, wb, ab, bb, pl, 0, rf, (unsigned)x);
-                    run_taps(IntTag<0>{}, ctr, prev);
+                    run_taps(IntTag<0>{}, ctr);
                 }
             }
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
-                flagged[j] = active ? __ballot(!(mabs[j] <= (float)R) && owner) : 0ull;
+                flagged[j] = active ? __ballot(fmask[j] != 0u && owner) : 0ull;
             if (p + 1 == kMaxPasses) break;
             Centre next;
-            if (!vote_next_window<R, WAVES, ROWS>(vote_slot, wv, active, flagged, rowy, wx0, ab, bb, pl, g,
-                                                  win, next))
+            if (!vote_next_window<R, WAVES, ROWS, WX, NWIN>(vote_slot, wv, active, flagged, rowy, wx0, ab,
+                                                            bb, pl, g, win, next, mine))
                 break;
-            if (p == 0) win.c1 = next;
-            else win.c2 = next;
-            ctr = next;
+            if (mine) {  // (else another window of the workgroup goes on: only its barriers matter here)
+                if (p == 0) win.c1 = next;
+                else win.c2 = next;
+                ctr = next;
+            }
         }
         if (!active) continue;  // (it has taken part in this frame's fills, barriers and votes)
 
+        // Taps that no window served: recomputed through clamped global gathers, overwriting what the
+        // first pass stored for them (same lane or same wave: program order).  Rows whose pixels have
+        // few such taps each went first (fix_few, right after the first pass and again here) ...
+        fix_few();
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) {
-            // taps that no window served: recomputed through clamped global gathers, overwriting
-            // what the first pass stored for them (same lane or same wave: program order)
-            unsigned long long todo = flagged[j];
-            const bool flag = !(mabs[j] <= (float)R);
+            // ... the others pixel by pixel by the whole wave, or lane by lane when there are many
+            unsigned long long todo = __ballot(fmask[j] != 0u && owner);
             if (todo) {  // wave-uniform, rare
-                float *gwn = gw ? gw + nb : nullptr, *goyn = goy ? goy + nb : nullptr,
-                      *goxn = gox ? gox + nb : nullptr;
                 if (__popcll(todo) <= kCoopMaxPixels) {
                     while (todo) {
                         const int b = __ffsll((long long)todo) - 1;
                         todo &= todo - 1;
                         const float sc = HEAD ? __shfl(occv[j], b) : 1.f;
-                        const float c = bwd_outside_coop<R>(ip, wb, ab, bb, gb_, gwn, goyn, goxn, g,
-                                                            win, rowy[j], wx0 + b, sc, HEAD);
+                        const float c = bwd_outside_coop(ip, wb, ab, bb, gb_, gwn, goyn, goxn, g,
+                                                         (unsigned)__shfl((int)fmask[j], b), rowy[j],
+                                                         wx0 + b, sc, HEAD);
                         if (HEAD && x == wx0 + b) gocc[j] += c;
                     }
-                } else if (flag) {
-                    const float c = bwd_outside_lane<R>(ip, wb, ab, bb, d[j][0], d[j][1], d[j][2], gwn,
-                                                        goyn, goxn, g, win, rowy[j],
-                                                        HEAD ? in_branch(x) : x,
-                                                        HEAD ? occv[j] : 1.f);
+                } else if (fmask[j]) {
+                    const float c = bwd_outside_lane(ip, wb, ab, bb, d[j][0], d[j][1], d[j][2], gwn,
+                                                     goyn, goxn, g, fmask[j], rowy[j],
+                                                     HEAD ? in_branch(x) : x,
+                                                     HEAD ? occv[j] : 1.f);
                     if (HEAD) gocc[j] += c;
                 }
             }

@@ -78,8 +78,9 @@ int make_geom(Geom &g, int N, int C, int H, int W, int k, int d)
     return make_geom_ex(g, N, C, H, W, k, d, H + halo, W + halo, 0, 0);
 }
 
+// the largest built radius (two 64-column windows of R = 16 would not fit the 160 KB of LDS)
 #ifndef SYNTH_DEFAULT_RADIUS
-#define SYNTH_DEFAULT_RADIUS 16
+#define SYNTH_DEFAULT_RADIUS 14
 #endif
 
 constexpr int kDefaultRadius = SYNTH_DEFAULT_RADIUS;
@@ -91,7 +92,7 @@ int pick_radius(int requested)
     if (requested <= 2) return 2;
     if (requested <= 4) return 4;
     if (requested <= 8) return 8;
-    return 16;
+    return 14;
 }
 
 bool tiled_ok(const Geom &g) { return g.k == 5 && g.d == 1 && g.C == 3; }
@@ -162,7 +163,7 @@ void dispatch_fwd_tiled(int R, const void *input, const float *weight, const flo
     case 2: launch_fwd_tiled<2, FT>(in, weight, offset_y, offset_x, output, g, st); break;
     case 4: launch_fwd_tiled<4, FT>(in, weight, offset_y, offset_x, output, g, st); break;
     case 8: launch_fwd_tiled<8, FT>(in, weight, offset_y, offset_x, output, g, st); break;
-    default: launch_fwd_tiled<16, FT>(in, weight, offset_y, offset_x, output, g, st); break;
+    default: launch_fwd_tiled<14, FT>(in, weight, offset_y, offset_x, output, g, st); break;
     }
 }
 
@@ -176,7 +177,7 @@ void dispatch_bwd_tiled(int R, const void *input, const float *weight, const flo
     case 2: launch_bwd_tiled<2, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, st); break;
     case 4: launch_bwd_tiled<4, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, st); break;
     case 8: launch_bwd_tiled<8, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, st); break;
-    default: launch_bwd_tiled<16, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, st); break;
+    default: launch_bwd_tiled<14, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, st); break;
     }
 }
 
@@ -188,7 +189,7 @@ void dispatch_head_fwd(int R, const float *w, const float *oy, const float *ox, 
     case 2: launch_head_fwd<2, FT>(w, oy, ox, out, g, ha, st); break;
     case 4: launch_head_fwd<4, FT>(w, oy, ox, out, g, ha, st); break;
     case 8: launch_head_fwd<8, FT>(w, oy, ox, out, g, ha, st); break;
-    default: launch_head_fwd<16, FT>(w, oy, ox, out, g, ha, st); break;
+    default: launch_head_fwd<14, FT>(w, oy, ox, out, g, ha, st); break;
     }
 }
 
@@ -201,7 +202,7 @@ void dispatch_head_bwd(int R, const float *w, const float *oy, const float *ox,
     case 2: launch_head_bwd<2, FT>(w, oy, ox, gout, gw, goy, gox, g, ha, st); break;
     case 4: launch_head_bwd<4, FT>(w, oy, ox, gout, gw, goy, gox, g, ha, st); break;
     case 8: launch_head_bwd<8, FT>(w, oy, ox, gout, gw, goy, gox, g, ha, st); break;
-    default: launch_head_bwd<16, FT>(w, oy, ox, gout, gw, goy, gox, g, ha, st); break;
+    default: launch_head_bwd<14, FT>(w, oy, ox, gout, gw, goy, gox, g, ha, st); break;
     }
 }
 
@@ -368,8 +369,8 @@ static int run_backward(const Geom &g, int rc, const void *input_any, const floa
             case 9: launch_gin_tiled<4, true>(weight, offset_y, offset_x, grad_output, grad_input, ws, g, bits, st); break;
             case 16: launch_gin_tiled<8, false>(weight, offset_y, offset_x, grad_output, grad_input, ws, g, bits, st); break;
             case 17: launch_gin_tiled<8, true>(weight, offset_y, offset_x, grad_output, grad_input, ws, g, bits, st); break;
-            case 32: launch_gin_tiled<16, false>(weight, offset_y, offset_x, grad_output, grad_input, ws, g, bits, st); break;
-            default: launch_gin_tiled<16, true>(weight, offset_y, offset_x, grad_output, grad_input, ws, g, bits, st); break;
+            case 28: launch_gin_tiled<14, false>(weight, offset_y, offset_x, grad_output, grad_input, ws, g, bits, st); break;
+            default: launch_gin_tiled<14, true>(weight, offset_y, offset_x, grad_output, grad_input, ws, g, bits, st); break;
             }
         } else if (!fixed) {
             if (k == 5 && C == 3)

@@ -1,4 +1,4 @@
-// synth_tiles.hip -- the LDS-staged kernels for ONE tile radius (-DSYNTH_TILE_R=2|4|8|16):
+// synth_tiles.hip -- the LDS-staged kernels for ONE tile radius (-DSYNTH_TILE_R=2|4|8|14):
 // explicit instantiations of the launchers declared in synth_device.hpp.  One object per radius
 // lets the heavily unrolled tap-major kernels compile in parallel.
 #include "synth_device.hpp"
@@ -16,15 +16,23 @@ namespace {
 
 // Tile configuration (tools/ab.py compares builds in one process; the SYNTH_* macros override the
 // shape for such experiments).  Every radius: 8 waves as 2 across x 4 down, 4 rows per wave =
-// 128 x 16 pixels, ONE workgroup per CU (LDS 53 / 64 / 88 / 140 KB for R = 2 / 4 / 8 / 16; the small
-// radii are padded with dynamic LDS so that a second workgroup does not fit).  Measured with
-// stream-only stand-ins (tools/exp/exp_stream.hip, backward-like, 1080p): 64 x 32 tiles, two
-// workgroups per CU 240 us; one per CU 231 us; 128 x 16, one per CU 224 us; 128 x 16, two per CU 241 us.
+// 128 x 16 pixels, ONE workgroup per CU (the small radii are padded with dynamic LDS so that a second
+// workgroup does not fit).  Measured with stream-only stand-ins (tools/exp/exp_stream.hip,
+// backward-like, 1080p): 64 x 32 tiles, two workgroups per CU 240 us; one per CU 231 us; 128 x 16,
+// one per CU 224 us; 128 x 16, two per CU 241 us.
+// The 128 pixels are served by NWIN = 2 staged windows of 64 columns each, every one with its own
+// centres (synth_device.hpp, "Several windows per tile"): the plane rows of a workgroup stay 512 B
+// long, which the DRAM wants, while a window only has to follow the motion of 64 x 16 pixels.
+// LDS: 2 x (16 + 5 + 2R) x (64 + 5 + 2R) x 16 B = 51 / 71 / 101 / 152 KB for R = 2 / 4 / 8 / 14 -- which
+// is why the largest radius is 14, not 16: two R = 16 windows would need 171 KB.
 #ifndef SYNTH_WAVES
 #define SYNTH_WAVES 8
 #endif
 #ifndef SYNTH_WX
 #define SYNTH_WX 2
+#endif
+#ifndef SYNTH_NWIN
+#define SYNTH_NWIN 2
 #endif
 #ifndef SYNTH_ROWS
 #define SYNTH_ROWS 4
@@ -38,16 +46,9 @@ namespace {
 
 template <int R>
 struct TileCfg {
-    static constexpr int WAVES = SYNTH_WAVES, WX = SYNTH_WX, ROWS = SYNTH_ROWS, OCC = SYNTH_OCC;
+    static constexpr int WAVES = SYNTH_WAVES, WX = SYNTH_WX, ROWS = SYNTH_ROWS, OCC = SYNTH_OCC,
+                         NWIN = SYNTH_NWIN;
     static constexpr bool kSolo = SYNTH_ONE_WG_PER_CU;
-};
-#ifndef SYNTH_R16_WX
-#define SYNTH_R16_WX 2
-#endif
-template <>
-struct TileCfg<16> {  // the macros above are for experiments at R <= 8
-    static constexpr int WAVES = 8, WX = SYNTH_R16_WX, ROWS = 4, OCC = 2;
-    static constexpr bool kSolo = true;
 };
 
 // Small grids: a problem with fewer than small_grid_tiles() (default 768) tiles of 64 x 32 pixels (the 64^2 and 128^2
@@ -66,13 +67,13 @@ struct TileCfg<16> {  // the macros above are for experiments at R <= 8
 #endif
 template <int R>
 struct BwdCfg {
-    static constexpr int WAVES = SYNTH_BWD_WAVES, WX = R == 16 ? SYNTH_R16_WX : 2, ROWS = SYNTH_BWD_ROWS,
-                         OCC = 2;
+    static constexpr int WAVES = SYNTH_BWD_WAVES, WX = SYNTH_WX, ROWS = SYNTH_BWD_ROWS, OCC = 2,
+                         NWIN = SYNTH_NWIN;
     static constexpr bool kSolo = true;
 };
 
 struct SmallCfg {
-    static constexpr int WAVES = 4, WX = 1, ROWS = 2, OCC = 2;
+    static constexpr int WAVES = 4, WX = 1, ROWS = 2, OCC = 2, NWIN = 1;
     static constexpr bool kSolo = false;
 };
 
@@ -80,8 +81,8 @@ struct SmallCfg {
 template <int R, class T>
 unsigned lds_pad()
 {
-    constexpr int TH = (T::WAVES / T::WX) * T::ROWS, TW = 64 * T::WX;
-    constexpr int bytes = TileShape<R, TH, TW>::LW * TileShape<R, TH, TW>::LH * 16;
+    constexpr int TH = (T::WAVES / T::WX) * T::ROWS, SW = 64 * T::WX / T::NWIN;
+    constexpr int bytes = T::NWIN * TileShape<R, TH, SW>::LW * TileShape<R, TH, SW>::LH * 16;
     return (T::kSolo && bytes < 82 * 1024) ? (unsigned)(82 * 1024 - bytes) : 0u;
 }
 
@@ -104,10 +105,10 @@ void fwd_cfg(bool head, const FT *in, const float *w, const float *oy, const flo
     const dim3 grid = asynth::tile_grid(g, (T::WAVES / T::WX) * T::ROWS, 64 * T::WX), block(64, T::WAVES);
     const unsigned pad = lds_pad<R, T>();
     if (head)
-        hipLaunchKernelGGL((synth_fwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true, FT, T::WX>), grid, block,
+        hipLaunchKernelGGL((synth_fwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true, FT, T::WX, T::NWIN>), grid, block,
                            pad, st, in, w, oy, ox, out, g, ha);
     else
-        hipLaunchKernelGGL((synth_fwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false, FT, T::WX>), grid, block,
+        hipLaunchKernelGGL((synth_fwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false, FT, T::WX, T::NWIN>), grid, block,
                            pad, st, in, w, oy, ox, out, g, ha);
 }
 
@@ -121,17 +122,17 @@ void bwd_cfg(bool head, const FT *in, const float *w, const float *oy, const flo
     const bool all = gw && goy && gox;
     if (head) {
         if (all)
-            hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true, true, FT, T::WX>), grid,
+            hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true, true, FT, T::WX, T::NWIN>), grid,
                                block, pad, st, in, w, oy, ox, gout, gw, goy, gox, g, ha);
         else
-            hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false, true, FT, T::WX>), grid,
+            hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false, true, FT, T::WX, T::NWIN>), grid,
                                block, pad, st, in, w, oy, ox, gout, gw, goy, gox, g, ha);
     } else {
         if (all)
-            hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true, false, FT, T::WX>), grid,
+            hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true, false, FT, T::WX, T::NWIN>), grid,
                                block, pad, st, in, w, oy, ox, gout, gw, goy, gox, g, ha);
         else
-            hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false, false, FT, T::WX>), grid,
+            hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false, false, FT, T::WX, T::NWIN>), grid,
                                block, pad, st, in, w, oy, ox, gout, gw, goy, gox, g, ha);
     }
 }
@@ -178,14 +179,14 @@ void launch_head_bwd(const float *w, const float *oy, const float *ox, const flo
 }
 
 // gradInput tiles: 64 x 16 pixels, 64-bit accumulators (3 x 29 x 77 x 8 B = 53.6 KB at R = 4,
-// 128.5 KB at R = 16: one workgroup per CU)
+// 114 KB at R = 14: one workgroup per CU)
 template <int R, bool FIXED>
 void launch_gin_tiled(const float *w, const float *oy, const float *ox, const float *gout, float *gin,
                       unsigned char *ws, const Geom &g, int bits, hipStream_t st)
 {
-    // 64 x 16 tiles; at R = 16 the tile fills the LDS (one workgroup per CU), so it gets 8 waves
-    // of 2 rows instead of 4 waves of 4 rows (415 -> 385 us at 1080p)
-    constexpr int WAVES = R == 16 ? 8 : 4, ROWS = R == 16 ? 2 : 4;
+    // 64 x 16 tiles; at the largest radius the tile takes most of the LDS (one workgroup per CU), so it
+    // gets 8 waves of 2 rows instead of 4 waves of 4 rows (415 -> 385 us at 1080p)
+    constexpr int WAVES = R > 8 ? 8 : 4, ROWS = R > 8 ? 2 : 4;
     hipLaunchKernelGGL((synth_gin_tiled<R, WAVES, ROWS, FIXED>), pixel_grid(g, WAVES * ROWS),
                        dim3(64, WAVES), 0, st, w, oy, ox, gout, gin, ws, g, bits);
 }

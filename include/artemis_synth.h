@@ -43,14 +43,16 @@ extern "C" {
 #define ARTEMIS_SYNTH_ABI_VERSION 1
 
 /* tile_radius: how far (in whole pixels) a tap may be displaced by its offsets and still be
- * served from the LDS-staged frame tile; larger displacements take a slower clamped global
- * gather, so every value is correct for any offset.  The displacement is measured from the tile's
- * own centre: when the mean offset at the middle of a workgroup's tile exceeds half the radius, the
- * staged window moves with it, so large coherent motion (a pan, a fast object) still runs from
- * LDS.  > 0 picks the smallest built tile radius that covers it; ARTEMIS_SYNTH_RADIUS_DEFAULT
- * lets the library choose; ARTEMIS_SYNTH_RADIUS_NONE disables LDS staging (direct gathers through
- * L1/L2).  Only k = 5, d = 1, C = 3 (the model's configuration: config.py:26-27) has an
- * LDS-staged kernel; other shapes always gather directly. */
+ * served from an LDS-staged window of the frame; larger displacements take a slower clamped global
+ * gather, so every value is correct for any offset.  The displacement is measured from the
+ * window's own centre: a window (64 x 16 output pixels) is staged around the displacement found at
+ * its middle, and when enough of its pixels still have taps outside it that share another coherent
+ * displacement (a motion boundary, a steep flow gradient), up to two more windows are staged around
+ * those -- so large coherent motion runs from LDS whatever its size.  > 0 picks the smallest built
+ * radius (2, 4, 8, 14) that covers it, 14 beyond; ARTEMIS_SYNTH_RADIUS_DEFAULT lets the library choose
+ * (14); ARTEMIS_SYNTH_RADIUS_NONE disables LDS staging (direct gathers through L1/L2).  Only k = 5,
+ * d = 1, C = 3 (the model's configuration: config.py:26-27) has an LDS-staged kernel; other shapes
+ * always gather directly. */
 #define ARTEMIS_SYNTH_RADIUS_DEFAULT (-1)
 #define ARTEMIS_SYNTH_RADIUS_NONE 0
 

@@ -143,9 +143,14 @@ def test_unpadded_is_bitwise_pad_then_op(dev, oracle, cfg, radius):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("radius", [-1, 0, 8])     # sigma 4: far taps at R = 8, no re-centring
+@pytest.mark.parametrize("radius", [-1, 0, 8])
 @pytest.mark.parametrize("padded_frame", [True, False])
 def test_row_strips_reproduce_the_full_frame(dev, oracle, padded_frame, radius):
+    """Strips reproduce the full frame bit for bit as long as a pixel's taps are computed the same
+    way whatever tile it falls in: direct gathers (radius 0), or the first LDS window plus the
+    per-pixel fix-up of a few stray taps (sigma 4 px at the default radius 14).  At radius 8 sigma 4
+    leaves most pixels with taps outside the first window; whether a tile then stages a further
+    window is decided per tile, so results agree to rounding only."""
     import artemis_amd
     from artemis_amd.sharding import row_strips
     H, W = 75, 131
@@ -164,8 +169,13 @@ def test_row_strips_reproduce_the_full_frame(dev, oracle, padded_frame, radius):
         sout, (sgi, sgw, sga, sgb) = run_frame(
             dev, lambda f, a, b, c: artemis_amd.synth_strip(f, a, b, c, y0, 1, padded=padded_frame),
             src, ws, oys, oxs, gs, radius, deterministic=True)
-        assert torch.equal(sout, out[sl])
-        assert torch.equal(sgw, gw[sl]) and torch.equal(sga, ga[sl]) and torch.equal(sgb, gb[sl])
+        if radius == 8:
+            for a, b, tol in ((sout, out[sl], FWD_RTOL), (sgw, gw[sl], BWD_RTOL), (sga, ga[sl], BWD_RTOL),
+                              (sgb, gb[sl], BWD_RTOL)):
+                assert float((a - b).abs().max()) <= tol * float(b.abs().max())
+        else:
+            assert torch.equal(sout, out[sl])
+            assert torch.equal(sgw, gw[sl]) and torch.equal(sga, ga[sl]) and torch.equal(sgb, gb[sl])
         gi_sum += sgi.double()
     close(gi_sum.float(), gi.cpu().numpy(), BWD_RTOL, "strip grad_input sum")
 
