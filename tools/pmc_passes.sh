@@ -1,14 +1,19 @@
 #!/bin/bash
 # rocprofv3 PMC passes for the synth kernels (run on the GPU box from the repo root).
 # One counter group per run (MI355X_MICROARCH.md: 8 SQ / 4 TCC slots; FETCH_SIZE=3, WRITE_SIZE=2).
-# usage: tools/pmc_passes.sh <outdir> [prof_run args...]
+# usage: [PROG=tools/pmc_calib.py] [PASSES="fetch write"] tools/pmc_passes.sh <outdir> [program args...]
 set -u
 OUT=$1; shift
 mkdir -p "$OUT"
+OUT=$(cd "$OUT" && pwd)
+PROG=${PROG:-tools/prof_run.py}
+PASSES=${PASSES:-"fetch write tcc sq1 sq2"}
 cd /tmp && export TMPDIR=/tmp
 run() {
   name=$1; shift
-  timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 "$GRAFT_REPO_ROOT/tools/prof_run.py" $EXTRA > "$OUT/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$OUT/$name.log"; exit 1; }
+  case " $PASSES " in *" $name "*) ;; *) return 0;; esac
+  timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 "$GRAFT_REPO_ROOT/$PROG" $EXTRA > "$OUT/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$OUT/$name.log"; exit 1; }
+  echo "pass $name ok"
 }
 EXTRA="$*"
 run fetch FETCH_SIZE
