@@ -720,24 +720,29 @@ __device__ __forceinline__ Centre unserved_centre(const float *__restrict__ ab,
 }
 
 // The vote after a pass: the waves of a window agree on whether to stage another one and where.
-//  1. Every wave reports how many of its pixels still have unserved taps; a window with fewer than
-//     kPassMinPixels of them is done (the fix-up handles a few pixels faster than a pass).
-//  2. Otherwise every wave with such pixels proposes a centre from its first one and votes for it
-//     only if it would pay: the candidate must serve at least 3/4 of the unserved taps of three
-//     other such pixels of the wave (first / last flagged row, first / last lane).  A window is
-//     staged when the waves in favour own at least half of the pixels in question, at the
-//     centre of the wave that owns most.  Independent large offsets (sigma = 4 px at R = 8: most
-//     pixels have a far tap or two, each in its own direction) fail that test in every wave, so
-//     they keep going straight to the fix-up and their bits do not depend on the tiling.
+//  1. Every wave reports how many of its pixels still have unserved taps, and the first of them; a
+//     window with fewer than kPassMinPixels such pixels is done (the fix-up handles a few pixels
+//     faster than a pass).
+//  2. Otherwise the candidate centre comes from a pixel of the wave that owns most of them -- the
+//     middle of the first run of such pixels in its row that has most (lowest wave on ties; every wave of the window derives it by itself: one 25-lane
+//     gather), and every wave counts how many of its pixels the candidate would serve, judged by each
+//     pixel's first unserved tap.  The window is staged when that is at least kPassMinPixels pixels
+//     and a third of all the pixels in question: a steep flow leaves pixels on BOTH sides of the first
+//     window (two populations of about half each, one further window apiece), while independent
+//     large offsets (sigma = 4 px at R = 8: most pixels have a far tap or two, each in its own
+//     direction) are served to a quarter at best by any centre and keep going straight to the
+//     fix-up.  A pass costs about as much as the per-pixel fix-up of a few dozen pixels.
 // A workgroup holds NWIN windows side by side (wave column c belongs to window c * NWIN / WX);
 // barriers are workgroup-wide, so the pass loop goes on while ANY window wants another pass
 // (return value) and `mine` says whether this wave's window does (then `next` is its centre).
-// flagged[j]: ballot of row j's pixels with unserved taps (owners only).  Contains one or two
-// barriers: every wave of the workgroup calls it, active or not.  slot: WAVES x 4 floats of LDS.
+// flagged[j]: ballot of row j's pixels with unserved taps (owners only); fmask[j]: this lane's
+// unserved taps in row j.  Contains one or two barriers: every wave of the workgroup calls it,
+// active or not.  slot: WAVES x 4 floats of LDS.
 template <int R, int WAVES, int ROWS, int WX, int NWIN>
 __device__ __forceinline__ bool vote_next_window(float *slot, int wv, bool active,
                                                  const unsigned long long (&flagged)[ROWS],
-                                                 const int (&rowy)[ROWS], int wx0,
+                                                 const unsigned (&fmask)[ROWS],
+                                                 const int (&rowy)[ROWS], int wx0, int x,
                                                  const float *__restrict__ ab,
                                                  const float *__restrict__ bb, size_t plane,
                                                  const Geom &g, const Windows &w, Centre &next,
@@ -745,31 +750,46 @@ __device__ __forceinline__ bool vote_next_window(float *slot, int wv, bool activ
 {
     constexpr int WXW = WX / NWIN;  // wave columns per window
     const int wi = (wv % WX) / WXW;
-    int cnt = 0, fy = 0, ly = 0;
-    unsigned long long fb = 0, lb = 0;
+    int cnt = 0, fy = 0;
+    unsigned long long fb = 0;
     if (active) {
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) {
             cnt += __popcll(flagged[j]);
-            if (flagged[j]) {
-                if (!fb) {
-                    fb = flagged[j];
-                    fy = rowy[j];
-                }
-                lb = flagged[j];
-                ly = rowy[j];
+            if (__popcll(flagged[j]) > __popcll(fb)) {  // the row with most such pixels
+                fb = flagged[j];
+                fy = rowy[j];
             }
         }
     }
     const bool lane0 = (threadIdx.x & 63) == 0;
-    if (lane0) slot[wv * 4 + 0] = (float)cnt;
+    if (lane0) {
+        slot[wv * 4 + 0] = (float)cnt;
+        slot[wv * 4 + 1] = (float)fy;
+        // the middle of the first run of such pixels: on a steep flow the run's displacements
+        // change steadily, and a window centred on its first pixel would spend half its reach on
+        // displacements beyond the run
+        const int first = fb ? __ffsll((long long)fb) - 1 : 0;
+        const unsigned long long rest = ~(fb >> first);
+        const int run = rest ? __ffsll((long long)rest) - 1 : 64 - first;
+        slot[wv * 4 + 2] = (float)(wx0 + first + run / 2);
+    }
     __syncthreads();
     float total[NWIN];
 #pragma unroll
     for (int k = 0; k < NWIN; ++k) total[k] = 0.f;
+    float total_mine = 0.f, most = 0.f, py = 0.f, pxl = 0.f;
 #pragma unroll
-    for (int i = 0; i < WAVES; ++i) total[(i % WX) / WXW] += slot[i * 4 + 0];
-    float total_mine = 0.f;
+    for (int i = 0; i < WAVES; ++i) {
+        const int k = (i % WX) / WXW;
+        const float c = slot[i * 4 + 0];
+        total[k] += c;
+        if (k == wi && c > most) {
+            most = c;
+            py = slot[i * 4 + 1];
+            pxl = slot[i * 4 + 2];
+        }
+    }
     bool open_any = false;
 #pragma unroll
     for (int k = 0; k < NWIN; ++k) {
@@ -780,60 +800,39 @@ __device__ __forceinline__ bool vote_next_window(float *slot, int wv, bool activ
     mine = false;
     if (!__builtin_amdgcn_readfirstlane((int)open_any)) return false;
 
-    Centre cand = {0.f, 0.f};
-    bool yes = false;
-    if (cnt && __builtin_amdgcn_readfirstlane((int)(total_mine >= (float)kPassMinPixels))) {
-        cand = unserved_centre<R>(ab, bb, plane, g, fy, wx0 + __ffsll((long long)fb) - 1, w, yes);
-        if (yes) {
-            const int sx[3] = {wx0 + 63 - __clzll((long long)fb), wx0 + __ffsll((long long)lb) - 1,
-                               wx0 + 63 - __clzll((long long)lb)};
-            const int sy[3] = {fy, ly, ly};
-            int all = 0, served = 0;
+    int would = 0;
+    if (__builtin_amdgcn_readfirstlane((int)(total_mine >= (float)kPassMinPixels))) {
+        bool ok;
+        next = unserved_centre<R>(ab, bb, plane, g, __builtin_amdgcn_readfirstlane((int)py),
+                                  __builtin_amdgcn_readfirstlane((int)pxl), w, ok);
+        if (ok && cnt) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                float ia, ib;
-                const bool far = unserved_tap<R>(ab, bb, plane, g, sy[i], sx[i], w, ia, ib);
-                all += __popcll(__ballot(far));
-                served += __popcll(__ballot(
-                    far && fabsf(ia - cand.y) <= (float)R && fabsf(ib - cand.x) <= (float)R));
+            for (int j = 0; j < ROWS; ++j) {
+                if (!flagged[j]) continue;  // wave-uniform
+                const int t = fmask[j] ? __ffs((int)fmask[j]) - 1 : 0;
+                const size_t o = (size_t)t * plane + (size_t)rowy[j] * g.W + x;
+                const float ia = (float)(int)ab[o], ib = (float)(int)bb[o];
+                would += __popcll(flagged[j] & __ballot(fabsf(ia - next.y) <= (float)R &&
+                                                        fabsf(ib - next.x) <= (float)R));
             }
-            yes = 4 * served >= 3 * all;
         }
+        if (!ok) would = -1;  // (the same in every wave of the window)
     }
-    if (lane0) {
-        slot[wv * 4 + 1] = yes ? (float)cnt : 0.f;
-        slot[wv * 4 + 2] = cand.y;
-        slot[wv * 4 + 3] = cand.x;
-    }
+    if (lane0) slot[wv * 4 + 3] = (float)would;
     __syncthreads();
-    float in_favour[NWIN], best[NWIN], ny[NWIN], nx[NWIN];
+    float served[NWIN];
 #pragma unroll
-    for (int k = 0; k < NWIN; ++k) in_favour[k] = best[k] = ny[k] = nx[k] = 0.f;
+    for (int k = 0; k < NWIN; ++k) served[k] = 0.f;
 #pragma unroll
-    for (int i = 0; i < WAVES; ++i) {
-        const int k = (i % WX) / WXW;
-        const float c = slot[i * 4 + 1];
-        in_favour[k] += c;
-        if (c > best[k]) {
-            best[k] = c;
-            ny[k] = slot[i * 4 + 2];
-            nx[k] = slot[i * 4 + 3];
-        }
-    }
+    for (int i = 0; i < WAVES; ++i) served[(i % WX) / WXW] += fmaxf(slot[i * 4 + 3], 0.f);
     bool again_any = false;
 #pragma unroll
     for (int k = 0; k < NWIN; ++k) {
-        const bool again = total[k] >= (float)kPassMinPixels && best[k] > 0.f &&
-                           2.f * in_favour[k] >= total[k];
+        const bool again = total[k] >= (float)kPassMinPixels && served[k] >= (float)kPassMinPixels &&
+                           3.f * served[k] >= total[k];
         again_any |= again;
-        if (k == wi) {
-            mine = again;
-            next.y = ny[k];
-            next.x = nx[k];
-        }
+        if (k == wi) mine = again;
     }
-    next.y = __builtin_amdgcn_readfirstlane(next.y);
-    next.x = __builtin_amdgcn_readfirstlane(next.x);
     mine = __builtin_amdgcn_readfirstlane((int)mine) != 0;
     return __builtin_amdgcn_readfirstlane((int)again_any) != 0;
 }
@@ -1128,6 +1127,29 @@ __device__ __forceinline__ void load_tap_col(TapCol<ROWS> &t, const float *__res
     }
 }
 
+// The same for a further pass: only the lanes whose pixel still has tap `tap` unserved fetch it
+// (a steep flow leaves contiguous strips of a row unserved: the other lanes' sectors are never
+// requested, so the pass moves the bytes of those pixels only).  The other lanes get zeros; their
+// tap is dropped by the caller's test of the same bit.
+template <int ROWS>
+__device__ __forceinline__ void load_tap_col_unserved(TapCol<ROWS> &t, const float *__restrict__ wbase,
+                                                      const float *__restrict__ abase,
+                                                      const float *__restrict__ bbase, size_t plane,
+                                                      int tap, const size_t (&rowoff)[ROWS], unsigned x,
+                                                      const unsigned (&fmask)[ROWS])
+{
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+        const size_t o = (size_t)tap * plane + rowoff[j];
+        t.w[j] = t.a[j] = t.b[j] = 0.f;
+        if ((fmask[j] >> tap) & 1u) {
+            t.w[j] = ld_stream(wbase + o + x);
+            t.a[j] = ld_stream(abase + o + x);
+            t.b[j] = ld_stream(bbase + o + x);
+        }
+    }
+}
+
 // Stage the clamped frame window.  Texels are fetched in batches with all of a batch's loads issued
 // before the first LDS write: left to itself hipcc waits vmcnt(0) after every texel, which
 // serialises ~14 L2 round trips (~10 us) at the head of every workgroup.  The batch size balances
@@ -1224,6 +1246,10 @@ __device__ __forceinline__ int in_branch(int v)
 }
 
 
+#ifdef SYNTH_DEV_TILE_CLOCK  // developer builds (tools/tile_clock.py): per-wave timeline of the forward
+static __device__ unsigned long long *g_tile_log;
+#endif
+
 template <int R, int WAVES, int ROWS, int OCC, bool HEAD, class FT, int WX = 1, int NWIN = 1>
 __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
     const FT *__restrict__ in, const float *__restrict__ w, const float *__restrict__ oy,
@@ -1239,6 +1265,11 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
     static_assert(WX % NWIN == 0, "wave columns must split evenly over the windows");
     __shared__ f32x4 tile_all[NWIN * LH * LW];
     __shared__ float vote_slot[WAVES * 4];
+#ifdef SYNTH_DEV_TILE_CLOCK
+    const unsigned long long dbg_t0 = wall_clock64();
+    unsigned long long dbg_t1 = 0, dbg_t2 = 0, dbg_a = 0, dbg_b = 0, dbg_c = 0;
+    int dbg_p = 0, dbg_left = 0;
+#endif
     int tx0, ty0;
     if (!tile_origin<TH, TW>(g, tx0, ty0)) return;
     const int n = blockIdx.z;
@@ -1311,18 +1342,13 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
         // One pass over the 25 taps with the window centred at `ctr`.  FIRST: the window is the
         // tile's first one (every tap it serves is added); otherwise only taps that it serves and
         // no earlier window (`prev`) did.
-        auto run_taps = [&](auto first_tag, const Centre ctr) {
-            constexpr bool FIRST = decltype(first_tag)::value != 0;
-            const int cbase = (((int)ctr.y) * LW + (int)ctr.x) * 16;  // the window's shift
-            static_for<0, 25>([&](auto tc) {
+        auto tap_body = [&](auto tc, auto first_tag, const TapCol<ROWS> &col, const Centre ctr, const int cbase) {
+                constexpr bool FIRST = decltype(first_tag)::value != 0;
                 constexpr int t = decltype(tc)::value;
                 constexpr int r = t / 5, s = t % 5;
-                TapCol<ROWS> nxt;
-                if (t < 24) load_tap_col<ROWS>(nxt, wb, ab, bb, pl, t + 1, rf, (unsigned)x);
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < ROWS; ++j) {
-                    const float wv = cur.w[j], a = cur.a[j], b = cur.b[j];
+                    const float wv = col.w[j], a = col.a[j], b = col.b[j];
                     const int ia = (int)a, ib = (int)b;
                     const float fa = a - (float)ia, fb = b - (float)ib;
                     const float reach = fmaxf(fabsf((float)ia - ctr.y), fabsf((float)ib - ctr.x));
@@ -1353,9 +1379,42 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
                     asm volatile("" : "+v"(acc0[j]), "+v"(acc1[j]), "+v"(acc2[j]), "+v"(fmask[j]));
                     if (j % kRowGroup == kRowGroup - 1) __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                cur = nxt;
-            });
+        };
+        // FIRST: the 25 taps in a software pipeline one tap deep -- every CU streams at once and the
+        // HBM is the limit.  A further pass runs on few CUs at a time from L2 / MALL and would expose
+        // one memory latency per tap (measured: 26-28 us per pass, as long as the first); it loads the
+        // operands of kGroup taps together instead.
+        auto run_taps = [&](auto first_tag, const Centre ctr) {
+            constexpr bool FIRST = decltype(first_tag)::value != 0;
+            const int cbase = (((int)ctr.y) * LW + (int)ctr.x) * 16;  // the window's shift
+            constexpr int kGroup = (ROWS > 2 && HEAD) ? 3 : 5;  // (what the 256 registers of two waves per SIMD hold)
+            if constexpr (FIRST) {
+                static_for<0, 25>([&](auto tc) {
+                    constexpr int t = decltype(tc)::value;
+                    TapCol<ROWS> nxt;
+                    if (t < 24) load_tap_col<ROWS>(nxt, wb, ab, bb, pl, t + 1, rf, (unsigned)x);
+                    __builtin_amdgcn_sched_barrier(0);
+                    tap_body(tc, first_tag, cur, ctr, cbase);
+                    __builtin_amdgcn_sched_barrier(0);
+                    cur = nxt;
+                });
+            } else {
+                static_for<0, (25 + kGroup - 1) / kGroup>([&](auto gc) {
+                    constexpr int t0 = decltype(gc)::value * kGroup;
+                    constexpr int nt = 25 - t0 < kGroup ? 25 - t0 : kGroup;
+                    TapCol<ROWS> col[kGroup];
+                    static_for<0, nt>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        load_tap_col_unserved<ROWS>(col[i], wb, ab, bb, pl, t0 + i, rf, (unsigned)x, fmask);
+                    });
+                    __builtin_amdgcn_sched_barrier(0);
+                    static_for<0, nt>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        tap_body(IntTag<t0 + i>{}, first_tag, col[i], ctr, cbase);
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                });
+            }
         };
 
         // Rows whose pixels have at most kMaskMaxTaps unserved taps each: every lane fixes its own
@@ -1388,6 +1447,9 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
             pl = per_frame(pl);
 #pragma unroll
             for (int j = 0; j < ROWS; ++j) rf[j] = per_frame(rf[j]);
+#ifdef SYNTH_DEV_TILE_CLOCK
+            if (p == 1) dbg_a = wall_clock64();
+#endif
             // every wave is done with the previous window (frame f - 1's last one; within a frame
             // the vote's barrier has already seen to that)
             if (HEAD && f > 0 && p == 0) __syncthreads();
@@ -1395,18 +1457,27 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
                 fill_tile_n<R, TH, 64 * (WAVES / NWIN), SW>(tile, ip, g, ty0 + g.oy0 - R + (int)ctr.y,
                                                             sx0 + g.ox0 - R + (int)ctr.x, tid);
             __syncthreads();
+#ifdef SYNTH_DEV_TILE_CLOCK
+            if (p == 1) dbg_b = wall_clock64();
+#endif
             if (p == 0) {
                 if (active) {
                     run_taps(IntTag<1>{}, ctr);
                     fix_few();
                 }
+#ifdef SYNTH_DEV_TILE_CLOCK
+                dbg_t1 = wall_clock64();
+#endif
             } else {
                 bool any = false;
 #pragma unroll
                 for (int j = 0; j < ROWS; ++j) any |= flagged[j] != 0;
                 if (mine && active && any) {  // wave-uniform
-                    load_tap_col<ROWS>(cur, wb, ab, bb, pl, 0, rf, (unsigned)x);
                     run_taps(IntTag<0>{}, ctr);
+#ifdef SYNTH_DEV_TILE_CLOCK
+                    dbg_p += 1;
+                    if (p == 1) dbg_c = wall_clock64();
+#endif
                 }
             }
 #pragma unroll
@@ -1414,8 +1485,8 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
                 flagged[j] = active ? __ballot(fmask[j] != 0u && owner) : 0ull;
             if (p + 1 == kMaxPasses) break;
             Centre next;
-            if (!vote_next_window<R, WAVES, ROWS, WX, NWIN>(vote_slot, wv, active, flagged, rowy, wx0, ab,
-                                                            bb, pl, g, win, next, mine))
+            if (!vote_next_window<R, WAVES, ROWS, WX, NWIN>(vote_slot, wv, active, flagged, fmask, rowy, wx0, x,
+                                                            ab, bb, pl, g, win, next, mine))
                 break;
             if (mine) {  // (else another window of the workgroup goes on: only its barriers matter here)
                 if (p == 0) win.c1 = next;
@@ -1424,6 +1495,9 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
             }
         }
         if (!active) continue;  // (it has taken part in this frame's fills, barriers and votes)
+#ifdef SYNTH_DEV_TILE_CLOCK
+        dbg_t2 = wall_clock64();
+#endif
 
         // Taps that no window served are added through clamped global gathers.  Rows whose pixels
         // have few such taps each went first (fix_few, right after the first pass and again here) ...
@@ -1432,6 +1506,9 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
         for (int j = 0; j < ROWS; ++j) {
             // ... the others pixel by pixel by the whole wave, or lane by lane when there are many
             unsigned long long todo = __ballot(fmask[j] != 0u && owner);
+#ifdef SYNTH_DEV_TILE_CLOCK
+            dbg_left += __popcll(todo);
+#endif
             if (todo) {  // wave-uniform, rare
                 const size_t o = rf[j] + x;
                 if (__popcll(todo) <= kCoopMaxPixels) {
@@ -1474,6 +1551,16 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
         st_stream(orow + plane + (unsigned)x, res1[j]);
         st_stream(orow + 2 * plane + (unsigned)x, res2[j]);
     }
+#ifdef SYNTH_DEV_TILE_CLOCK
+    if (g_tile_log && threadIdx.x == 0) {
+        unsigned long long *q =
+            g_tile_log + ((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * WAVES + wv) * 12;
+        q[0] = dbg_t0, q[1] = dbg_t1, q[2] = dbg_t2, q[3] = wall_clock64();
+        q[4] = dbg_p, q[5] = dbg_left, q[6] = (unsigned long long)(unsigned)tx0 << 32 | (unsigned)ty0;
+        q[7] = __smid();
+        q[8] = dbg_a, q[9] = dbg_b, q[10] = dbg_c;
+    }
+#endif
 }
 
 // HEAD = true: the fused ChronoSynth head's backward.  gradOutput is the gradient of
@@ -1559,18 +1646,13 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
         // three gradients of every tap are stored (those of a tap the window does not serve are
         // overwritten later -- same lane or same wave, program order); otherwise only the taps
         // that this window serves and no earlier one did are stored.
-        auto run_taps = [&](auto first_tag, const Centre ctr) {
-            constexpr bool FIRST = decltype(first_tag)::value != 0;
-            const int cbase = (((int)ctr.y) * LW + (int)ctr.x) * 16;  // the window's shift
-            static_for<0, 25>([&](auto tc) {
+        auto tap_body = [&](auto tc, auto first_tag, const TapCol<ROWS> &col, const Centre ctr, const int cbase) {
+                constexpr bool FIRST = decltype(first_tag)::value != 0;
                 constexpr int t = decltype(tc)::value;
                 constexpr int r = t / 5, s = t % 5;
-                TapCol<ROWS> nxt;
-                if (t < 24) load_tap_col<ROWS>(nxt, wb, ab, bb, pl, t + 1, rf, (unsigned)x);
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < ROWS; ++j) {
-                    const float wv = cur.w[j], a = cur.a[j], b = cur.b[j];
+                    const float wv = col.w[j], a = col.a[j], b = col.b[j];
                     const int ia = (int)a, ib = (int)b;
                     const float fa = a - (float)ia, fb = b - (float)ib;
                     const float reach = fmaxf(fabsf((float)ia - ctr.y), fabsf((float)ib - ctr.x));
@@ -1612,9 +1694,39 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
                     asm volatile("" : "+v"(fmask[j]));
                     if (j % kRowGroup == kRowGroup - 1) __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                cur = nxt;
-            });
+        };
+        // (pipelined first pass, a tap row's loads together in further passes: see forward)
+        auto run_taps = [&](auto first_tag, const Centre ctr) {
+            constexpr bool FIRST = decltype(first_tag)::value != 0;
+            const int cbase = (((int)ctr.y) * LW + (int)ctr.x) * 16;  // the window's shift
+            constexpr int kGroup = 5;
+            if constexpr (FIRST) {
+                static_for<0, 25>([&](auto tc) {
+                    constexpr int t = decltype(tc)::value;
+                    TapCol<ROWS> nxt;
+                    if (t < 24) load_tap_col<ROWS>(nxt, wb, ab, bb, pl, t + 1, rf, (unsigned)x);
+                    __builtin_amdgcn_sched_barrier(0);
+                    tap_body(tc, first_tag, cur, ctr, cbase);
+                    __builtin_amdgcn_sched_barrier(0);
+                    cur = nxt;
+                });
+            } else {
+                static_for<0, (25 + kGroup - 1) / kGroup>([&](auto gc) {
+                    constexpr int t0 = decltype(gc)::value * kGroup;
+                    constexpr int nt = 25 - t0 < kGroup ? 25 - t0 : kGroup;
+                    TapCol<ROWS> col[kGroup];
+                    static_for<0, nt>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        load_tap_col_unserved<ROWS>(col[i], wb, ab, bb, pl, t0 + i, rf, (unsigned)x, fmask);
+                    });
+                    __builtin_amdgcn_sched_barrier(0);
+                    static_for<0, nt>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        tap_body(IntTag<t0 + i>{}, first_tag, col[i], ctr, cbase);
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                });
+            }
         };
 
         // Rows whose pixels have at most kMaskMaxTaps unserved taps each (see forward): every lane
@@ -1687,7 +1799,6 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
 #pragma unroll
                 for (int j = 0; j < ROWS; ++j) any |= flagged[j] != 0;
                 if (mine && active && any) {  // wave-uniform
-                    load_tap_col<ROWS>(cur, wb, ab, bb, pl, 0, rf, (unsigned)x);
                     run_taps(IntTag<0>{}, ctr);
                 }
             }
@@ -1696,8 +1807,8 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
                 flagged[j] = active ? __ballot(fmask[j] != 0u && owner) : 0ull;
             if (p + 1 == kMaxPasses) break;
             Centre next;
-            if (!vote_next_window<R, WAVES, ROWS, WX, NWIN>(vote_slot, wv, active, flagged, rowy, wx0, ab,
-                                                            bb, pl, g, win, next, mine))
+            if (!vote_next_window<R, WAVES, ROWS, WX, NWIN>(vote_slot, wv, active, flagged, fmask, rowy, wx0, x,
+                                                            ab, bb, pl, g, win, next, mine))
                 break;
             if (mine) {  // (else another window of the workgroup goes on: only its barriers matter here)
                 if (p == 0) win.c1 = next;
@@ -1751,7 +1862,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
 // ds_add_u64 on fixed-point integers (planar [c][ly][lx]: a wave's lanes hit consecutive banks),
 // then flushes the tile with one global atomic per touched texel (~5 per pixel).  Taps displaced
 // beyond the tile radius are left out of the LDS pass and sent to memory individually afterwards
-// (same |offset| < R + 1 test in both passes, so every contribution lands exactly once).
+// (a per-lane bit mask from the LDS pass says which, so every contribution lands exactly once).
 // FIXED (deterministic mode): the flush adds the integers into the int64 image of the workspace,
 // so the result does not depend on any order; otherwise each tile sum is converted to fp32 and
 // added to gradInput with float atomics.  Same tap-major streaming order as the other kernels.
@@ -1813,7 +1924,7 @@ __global__ __launch_bounds__(64 * WAVES) void synth_gin_tiled(const float *__res
     __syncthreads();
 
     float d[ROWS][3];
-    float mabs[ROWS];
+    unsigned fm[ROWS];  // bit t: tap t of this lane's pixel leaves the window (goes to memory below)
     int rowbase[ROWS];
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) {
@@ -1821,7 +1932,7 @@ __global__ __launch_bounds__(64 * WAVES) void synth_gin_tiled(const float *__res
         d[j][0] = ld_stream(gb_ + roff[j] + (unsigned)x) * on;
         d[j][1] = ld_stream(gb_ + plane + roff[j] + (unsigned)x) * on;
         d[j][2] = ld_stream(gb_ + 2 * plane + roff[j] + (unsigned)x) * on;
-        mabs[j] = 0.f;
+        fm[j] = 0u;
         rowbase[j] = (rowy[j] - ty0 + R - cyi) * LW + px + R - cxi;
     }
     static_for<0, 25>([&](auto tc) {
@@ -1836,7 +1947,7 @@ __global__ __launch_bounds__(64 * WAVES) void synth_gin_tiled(const float *__res
             const int ia = (int)a, ib = (int)b;
             const float fa = a - (float)ia, fb = b - (float)ib;
             const float reach = fmaxf(fabsf((float)ia - ctr.y), fabsf((float)ib - ctr.x));
-            mabs[j] = fmaxf(mabs[j], reach);
+            fm[j] |= reach <= (float)R ? 0u : 1u << t;
             if (reach <= (float)R) {  // footprint inside the window
                 acc_t *p = acc + (__mul24(ia, LW) + ib + rowbase[j] + (r * LW + s));
                 const float ga = 1.f - fa, gb = 1.f - fb;
@@ -1850,7 +1961,7 @@ __global__ __launch_bounds__(64 * WAVES) void synth_gin_tiled(const float *__res
                     atomicAdd(p + c * CS + LW + 1, to_fixed(dw * c11));
                 }
             }
-            asm volatile("" : "+v"(mabs[j]));
+            asm volatile("" : "+v"(fm[j]));
         }
         __builtin_amdgcn_sched_barrier(0);
         cur = nxt;
@@ -1875,18 +1986,20 @@ __global__ __launch_bounds__(64 * WAVES) void synth_gin_tiled(const float *__res
         }
     }
 
-    // taps that left the tile: straight to memory, lane by lane (rare)
+    // taps that left the window: straight to memory.  Every lane walks the set bits of its own mask,
+    // all lanes of the row together: as many steps as the worst pixel has such taps (sigma = 4 px: one
+    // or two; the first version walked all 25 taps of any pixel that had one: 25 dependent round trips)
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) {
-        if (!(mabs[j] <= (float)R) && lane_on && rowon[j]) {
-            const int y = rowy[j];
-            const size_t pix = roff[j] + x;
-#pragma unroll 1
-            for (int t = 0; t < 25; ++t) {
+        unsigned m = (lane_on && rowon[j]) ? fm[j] : 0u;
+        const int y = rowy[j];
+        const size_t pix = roff[j] + x;
+        while (__ballot(m != 0u)) {  // wave-uniform
+            if (m) {
+                const int t = __ffs((int)m) - 1;
+                m &= m - 1;
                 const size_t o = (size_t)t * plane + pix;
-                const float a = ab[o], b = bb[o];
-                if (tap_in_tile<R>(a, b, ctr)) continue;
-                const float wv = wb[o];
+                const float a = ab[o], b = bb[o], wv = wb[o];
                 const int r = t / 5, s2 = t - 5 * r;
                 const TapIdx ti = tap_index(g, a, b, y + g.oy0 + r, x + g.ox0 + s2);
                 const float ga = 1.f - ti.fa, gb = 1.f - ti.fb;

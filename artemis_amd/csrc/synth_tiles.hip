@@ -192,6 +192,15 @@ void launch_gin_tiled(const float *w, const float *oy, const float *ox, const fl
 }
 
 
+#if defined(SYNTH_DEV_TILE_CLOCK) && SYNTH_TILE_R == 14 && !SYNTH_TILE_BF16
+}  // namespace asynth
+extern "C" int artemis_synth_dev_set_tile_log(void *p)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_tile_log), &p, sizeof(p));
+}
+namespace asynth {
+#endif
+
 #if SYNTH_TILE_BF16
 typedef bf16_t frame_t;
 #else

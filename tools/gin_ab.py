@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""A/B of gradInput (atomic mode) across builds in one process.  usage: gin_ab.py lib... [--radius R]"""
+"""A/B of gradInput (atomic mode) across builds in one process.
+usage: gin_ab.py lib... [--radius=R] [--regime=sigma:4|smooth30|pan]"""
 import os, statistics, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,14 +9,17 @@ import bench
 from tools.ab import bind
 
 radius = -1
+regime = None
 libs = []
 for a in sys.argv[1:]:
     if a.startswith("--radius="):
         radius = int(a.split("=")[1])
+    elif a.startswith("--regime="):
+        regime = a.split("=")[1]
     else:
         libs.append((os.path.basename(a), bind(os.path.join(ROOT, a))))
 dev = torch.device("cuda:0")
-frames = bench.make_frames(1, 1.0, dev, 103)
+frames = bench.make_frames(1, 1.0, dev, 103, regime=regime)
 st = torch.cuda.current_stream().cuda_stream
 H, W = bench.H, bench.W
 gin = torch.empty_like(frames[0]["inp"])
@@ -35,4 +39,4 @@ for rnd in range(8):
         if rnd:
             T[name].append(e0.elapsed_time(e1))
 for n, ts in T.items():
-    print(f"{n:28s} gin atomic r={radius}: median {statistics.median(ts)*1e3:8.1f} us  min {min(ts)*1e3:8.1f}")
+    print(f"{n:28s} gin atomic r={radius} {regime or 'sigma:1'}: median {statistics.median(ts)*1e3:8.1f} us  min {min(ts)*1e3:8.1f}")
