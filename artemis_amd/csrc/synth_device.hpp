@@ -651,6 +651,7 @@ __device__ __forceinline__ Centre tile_centre(const float *__restrict__ ab,
 #endif
 constexpr int kMaxPasses = SYNTH_MAX_PASSES;
 constexpr int kPassMinPixels = SYNTH_PASS_MIN_PIXELS;  // pixels with unserved taps that justify a pass
+constexpr int kVoteSlots = 4;                          // floats of LDS per wave for the vote
 constexpr float kNoCentre = 1.0e30f;                   // a window that serves nothing
 
 struct Windows {
@@ -724,9 +725,9 @@ __device__ __forceinline__ Centre unserved_centre(const float *__restrict__ ab,
 //     window with fewer than kPassMinPixels such pixels is done (the fix-up handles a few pixels
 //     faster than a pass).
 //  2. Otherwise the candidate centre comes from a pixel of the wave that owns most of them -- the
-//     middle of the first run of such pixels in its row that has most (lowest wave on ties; every wave of the window derives it by itself: one 25-lane
-//     gather), and every wave counts how many of its pixels the candidate would serve, judged by each
-//     pixel's first unserved tap.  The window is staged when that is at least kPassMinPixels pixels
+//     middle of the first run of such pixels in its row that has most (lowest wave on ties; every
+//     wave of the window derives it by itself: one 25-lane gather), and every wave counts how many
+//     of its pixels the candidate would serve, judged by each pixel's first and last unserved tap.  The window is staged when that is at least kPassMinPixels pixels
 //     and a third of all the pixels in question: a steep flow leaves pixels on BOTH sides of the first
 //     window (two populations of about half each, one further window apiece), while independent
 //     large offsets (sigma = 4 px at R = 8: most pixels have a far tap or two, each in its own
@@ -764,15 +765,15 @@ __device__ __forceinline__ bool vote_next_window(float *slot, int wv, bool activ
     }
     const bool lane0 = (threadIdx.x & 63) == 0;
     if (lane0) {
-        slot[wv * 4 + 0] = (float)cnt;
-        slot[wv * 4 + 1] = (float)fy;
+        slot[wv * kVoteSlots + 0] = (float)cnt;
+        slot[wv * kVoteSlots + 1] = (float)fy;
         // the middle of the first run of such pixels: on a steep flow the run's displacements
         // change steadily, and a window centred on its first pixel would spend half its reach on
         // displacements beyond the run
         const int first = fb ? __ffsll((long long)fb) - 1 : 0;
         const unsigned long long rest = ~(fb >> first);
         const int run = rest ? __ffsll((long long)rest) - 1 : 64 - first;
-        slot[wv * 4 + 2] = (float)(wx0 + first + run / 2);
+        slot[wv * kVoteSlots + 2] = (float)(wx0 + first + run / 2);
     }
     __syncthreads();
     float total[NWIN];
@@ -782,12 +783,12 @@ __device__ __forceinline__ bool vote_next_window(float *slot, int wv, bool activ
 #pragma unroll
     for (int i = 0; i < WAVES; ++i) {
         const int k = (i % WX) / WXW;
-        const float c = slot[i * 4 + 0];
+        const float c = slot[i * kVoteSlots + 0];
         total[k] += c;
         if (k == wi && c > most) {
             most = c;
-            py = slot[i * 4 + 1];
-            pxl = slot[i * 4 + 2];
+            py = slot[i * kVoteSlots + 1];
+            pxl = slot[i * kVoteSlots + 2];
         }
     }
     bool open_any = false;
@@ -809,22 +810,28 @@ __device__ __forceinline__ bool vote_next_window(float *slot, int wv, bool activ
 #pragma unroll
             for (int j = 0; j < ROWS; ++j) {
                 if (!flagged[j]) continue;  // wave-uniform
-                const int t = fmask[j] ? __ffs((int)fmask[j]) - 1 : 0;
-                const size_t o = (size_t)t * plane + (size_t)rowy[j] * g.W + x;
-                const float ia = (float)(int)ab[o], ib = (float)(int)bb[o];
-                would += __popcll(flagged[j] & __ballot(fabsf(ia - next.y) <= (float)R &&
-                                                        fabsf(ib - next.x) <= (float)R));
+                // (the first AND the last of a pixel's unserved taps: coherent motion passes both,
+                // independent far taps rarely do)
+                const int t1 = fmask[j] ? __ffs((int)fmask[j]) - 1 : 0;
+                const int t2 = fmask[j] ? 31 - __clz((int)fmask[j]) : 0;
+                const size_t o = (size_t)rowy[j] * g.W + x;
+                const size_t o1 = (size_t)t1 * plane + o, o2 = (size_t)t2 * plane + o;
+                const float ia1 = (float)(int)ab[o1], ib1 = (float)(int)bb[o1];
+                const float ia2 = (float)(int)ab[o2], ib2 = (float)(int)bb[o2];
+                would += __popcll(flagged[j] &
+                                  __ballot(fabsf(ia1 - next.y) <= (float)R && fabsf(ib1 - next.x) <= (float)R &&
+                                           fabsf(ia2 - next.y) <= (float)R && fabsf(ib2 - next.x) <= (float)R));
             }
         }
         if (!ok) would = -1;  // (the same in every wave of the window)
     }
-    if (lane0) slot[wv * 4 + 3] = (float)would;
+    if (lane0) slot[wv * kVoteSlots + 3] = (float)would;
     __syncthreads();
     float served[NWIN];
 #pragma unroll
     for (int k = 0; k < NWIN; ++k) served[k] = 0.f;
 #pragma unroll
-    for (int i = 0; i < WAVES; ++i) served[(i % WX) / WXW] += fmaxf(slot[i * 4 + 3], 0.f);
+    for (int i = 0; i < WAVES; ++i) served[(i % WX) / WXW] += fmaxf(slot[i * kVoteSlots + 3], 0.f);
     bool again_any = false;
 #pragma unroll
     for (int k = 0; k < NWIN; ++k) {
@@ -1127,29 +1134,6 @@ __device__ __forceinline__ void load_tap_col(TapCol<ROWS> &t, const float *__res
     }
 }
 
-// The same for a further pass: only the lanes whose pixel still has tap `tap` unserved fetch it
-// (a steep flow leaves contiguous strips of a row unserved: the other lanes' sectors are never
-// requested, so the pass moves the bytes of those pixels only).  The other lanes get zeros; their
-// tap is dropped by the caller's test of the same bit.
-template <int ROWS>
-__device__ __forceinline__ void load_tap_col_unserved(TapCol<ROWS> &t, const float *__restrict__ wbase,
-                                                      const float *__restrict__ abase,
-                                                      const float *__restrict__ bbase, size_t plane,
-                                                      int tap, const size_t (&rowoff)[ROWS], unsigned x,
-                                                      const unsigned (&fmask)[ROWS])
-{
-#pragma unroll
-    for (int j = 0; j < ROWS; ++j) {
-        const size_t o = (size_t)tap * plane + rowoff[j];
-        t.w[j] = t.a[j] = t.b[j] = 0.f;
-        if ((fmask[j] >> tap) & 1u) {
-            t.w[j] = ld_stream(wbase + o + x);
-            t.a[j] = ld_stream(abase + o + x);
-            t.b[j] = ld_stream(bbase + o + x);
-        }
-    }
-}
-
 // Stage the clamped frame window.  Texels are fetched in batches with all of a batch's loads issued
 // before the first LDS write: left to itself hipcc waits vmcnt(0) after every texel, which
 // serialises ~14 L2 round trips (~10 us) at the head of every workgroup.  The batch size balances
@@ -1264,7 +1248,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
     constexpr int LW = TileShape<R, TH, SW>::LW, LH = TileShape<R, TH, SW>::LH;
     static_assert(WX % NWIN == 0, "wave columns must split evenly over the windows");
     __shared__ f32x4 tile_all[NWIN * LH * LW];
-    __shared__ float vote_slot[WAVES * 4];
+    __shared__ float vote_slot[WAVES * kVoteSlots];
 #ifdef SYNTH_DEV_TILE_CLOCK
     const unsigned long long dbg_t0 = wall_clock64();
     unsigned long long dbg_t1 = 0, dbg_t2 = 0, dbg_a = 0, dbg_b = 0, dbg_c = 0;
@@ -1342,13 +1326,18 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
         // One pass over the 25 taps with the window centred at `ctr`.  FIRST: the window is the
         // tile's first one (every tap it serves is added); otherwise only taps that it serves and
         // no earlier window (`prev`) did.
-        auto tap_body = [&](auto tc, auto first_tag, const TapCol<ROWS> &col, const Centre ctr, const int cbase) {
-                constexpr bool FIRST = decltype(first_tag)::value != 0;
+        auto run_taps = [&](auto first_tag, const Centre ctr) {
+            constexpr bool FIRST = decltype(first_tag)::value != 0;
+            const int cbase = (((int)ctr.y) * LW + (int)ctr.x) * 16;  // the window's shift
+            static_for<0, 25>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
                 constexpr int r = t / 5, s = t % 5;
+                TapCol<ROWS> nxt;
+                if (t < 24) load_tap_col<ROWS>(nxt, wb, ab, bb, pl, t + 1, rf, (unsigned)x);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < ROWS; ++j) {
-                    const float wv = col.w[j], a = col.a[j], b = col.b[j];
+                    const float wv = cur.w[j], a = cur.a[j], b = cur.b[j];
                     const int ia = (int)a, ib = (int)b;
                     const float fa = a - (float)ia, fb = b - (float)ib;
                     const float reach = fmaxf(fabsf((float)ia - ctr.y), fabsf((float)ib - ctr.x));
@@ -1379,42 +1368,9 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
                     asm volatile("" : "+v"(acc0[j]), "+v"(acc1[j]), "+v"(acc2[j]), "+v"(fmask[j]));
                     if (j % kRowGroup == kRowGroup - 1) __builtin_amdgcn_sched_barrier(0);
                 }
-        };
-        // FIRST: the 25 taps in a software pipeline one tap deep -- every CU streams at once and the
-        // HBM is the limit.  A further pass runs on few CUs at a time from L2 / MALL and would expose
-        // one memory latency per tap (measured: 26-28 us per pass, as long as the first); it loads the
-        // operands of kGroup taps together instead.
-        auto run_taps = [&](auto first_tag, const Centre ctr) {
-            constexpr bool FIRST = decltype(first_tag)::value != 0;
-            const int cbase = (((int)ctr.y) * LW + (int)ctr.x) * 16;  // the window's shift
-            constexpr int kGroup = (ROWS > 2 && HEAD) ? 3 : 5;  // (what the 256 registers of two waves per SIMD hold)
-            if constexpr (FIRST) {
-                static_for<0, 25>([&](auto tc) {
-                    constexpr int t = decltype(tc)::value;
-                    TapCol<ROWS> nxt;
-                    if (t < 24) load_tap_col<ROWS>(nxt, wb, ab, bb, pl, t + 1, rf, (unsigned)x);
-                    __builtin_amdgcn_sched_barrier(0);
-                    tap_body(tc, first_tag, cur, ctr, cbase);
-                    __builtin_amdgcn_sched_barrier(0);
-                    cur = nxt;
-                });
-            } else {
-                static_for<0, (25 + kGroup - 1) / kGroup>([&](auto gc) {
-                    constexpr int t0 = decltype(gc)::value * kGroup;
-                    constexpr int nt = 25 - t0 < kGroup ? 25 - t0 : kGroup;
-                    TapCol<ROWS> col[kGroup];
-                    static_for<0, nt>([&](auto ic) {
-                        constexpr int i = decltype(ic)::value;
-                        load_tap_col_unserved<ROWS>(col[i], wb, ab, bb, pl, t0 + i, rf, (unsigned)x, fmask);
-                    });
-                    __builtin_amdgcn_sched_barrier(0);
-                    static_for<0, nt>([&](auto ic) {
-                        constexpr int i = decltype(ic)::value;
-                        tap_body(IntTag<t0 + i>{}, first_tag, col[i], ctr, cbase);
-                        __builtin_amdgcn_sched_barrier(0);
-                    });
-                });
-            }
+                __builtin_amdgcn_sched_barrier(0);
+                cur = nxt;
+            });
         };
 
         // Rows whose pixels have at most kMaskMaxTaps unserved taps each: every lane fixes its own
@@ -1473,6 +1429,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
 #pragma unroll
                 for (int j = 0; j < ROWS; ++j) any |= flagged[j] != 0;
                 if (mine && active && any) {  // wave-uniform
+                    load_tap_col<ROWS>(cur, wb, ab, bb, pl, 0, rf, (unsigned)x);
                     run_taps(IntTag<0>{}, ctr);
 #ifdef SYNTH_DEV_TILE_CLOCK
                     dbg_p += 1;
@@ -1582,7 +1539,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
     constexpr int LW = TileShape<R, TH, SW>::LW, LH = TileShape<R, TH, SW>::LH;
     static_assert(WX % NWIN == 0, "wave columns must split evenly over the windows");
     __shared__ f32x4 tile_all[NWIN * LH * LW];
-    __shared__ float vote_slot[WAVES * 4];
+    __shared__ float vote_slot[WAVES * kVoteSlots];
     int tx0, ty0;
     if (!tile_origin<TH, TW>(g, tx0, ty0)) return;
     const int n = blockIdx.z;
@@ -1646,13 +1603,18 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
         // three gradients of every tap are stored (those of a tap the window does not serve are
         // overwritten later -- same lane or same wave, program order); otherwise only the taps
         // that this window serves and no earlier one did are stored.
-        auto tap_body = [&](auto tc, auto first_tag, const TapCol<ROWS> &col, const Centre ctr, const int cbase) {
-                constexpr bool FIRST = decltype(first_tag)::value != 0;
+        auto run_taps = [&](auto first_tag, const Centre ctr) {
+            constexpr bool FIRST = decltype(first_tag)::value != 0;
+            const int cbase = (((int)ctr.y) * LW + (int)ctr.x) * 16;  // the window's shift
+            static_for<0, 25>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
                 constexpr int r = t / 5, s = t % 5;
+                TapCol<ROWS> nxt;
+                if (t < 24) load_tap_col<ROWS>(nxt, wb, ab, bb, pl, t + 1, rf, (unsigned)x);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < ROWS; ++j) {
-                    const float wv = col.w[j], a = col.a[j], b = col.b[j];
+                    const float wv = cur.w[j], a = cur.a[j], b = cur.b[j];
                     const int ia = (int)a, ib = (int)b;
                     const float fa = a - (float)ia, fb = b - (float)ib;
                     const float reach = fmaxf(fabsf((float)ia - ctr.y), fabsf((float)ib - ctr.x));
@@ -1694,39 +1656,9 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
                     asm volatile("" : "+v"(fmask[j]));
                     if (j % kRowGroup == kRowGroup - 1) __builtin_amdgcn_sched_barrier(0);
                 }
-        };
-        // (pipelined first pass, a tap row's loads together in further passes: see forward)
-        auto run_taps = [&](auto first_tag, const Centre ctr) {
-            constexpr bool FIRST = decltype(first_tag)::value != 0;
-            const int cbase = (((int)ctr.y) * LW + (int)ctr.x) * 16;  // the window's shift
-            constexpr int kGroup = 5;
-            if constexpr (FIRST) {
-                static_for<0, 25>([&](auto tc) {
-                    constexpr int t = decltype(tc)::value;
-                    TapCol<ROWS> nxt;
-                    if (t < 24) load_tap_col<ROWS>(nxt, wb, ab, bb, pl, t + 1, rf, (unsigned)x);
-                    __builtin_amdgcn_sched_barrier(0);
-                    tap_body(tc, first_tag, cur, ctr, cbase);
-                    __builtin_amdgcn_sched_barrier(0);
-                    cur = nxt;
-                });
-            } else {
-                static_for<0, (25 + kGroup - 1) / kGroup>([&](auto gc) {
-                    constexpr int t0 = decltype(gc)::value * kGroup;
-                    constexpr int nt = 25 - t0 < kGroup ? 25 - t0 : kGroup;
-                    TapCol<ROWS> col[kGroup];
-                    static_for<0, nt>([&](auto ic) {
-                        constexpr int i = decltype(ic)::value;
-                        load_tap_col_unserved<ROWS>(col[i], wb, ab, bb, pl, t0 + i, rf, (unsigned)x, fmask);
-                    });
-                    __builtin_amdgcn_sched_barrier(0);
-                    static_for<0, nt>([&](auto ic) {
-                        constexpr int i = decltype(ic)::value;
-                        tap_body(IntTag<t0 + i>{}, first_tag, col[i], ctr, cbase);
-                        __builtin_amdgcn_sched_barrier(0);
-                    });
-                });
-            }
+                __builtin_amdgcn_sched_barrier(0);
+                cur = nxt;
+            });
         };
 
         // Rows whose pixels have at most kMaskMaxTaps unserved taps each (see forward): every lane
@@ -1799,6 +1731,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
 #pragma unroll
                 for (int j = 0; j < ROWS; ++j) any |= flagged[j] != 0;
                 if (mine && active && any) {  // wave-uniform
+                    load_tap_col<ROWS>(cur, wb, ab, bb, pl, 0, rf, (unsigned)x);
                     run_taps(IntTag<0>{}, ctr);
                 }
             }
