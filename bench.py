@@ -329,7 +329,7 @@ def run_train(args, rank, world, device, dist, backend):
     op = Op(lib, frames, B, args.radius, stream)
 
     def barrier():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
 
     events = []
@@ -346,7 +346,7 @@ def run_train(args, rank, world, device, dist, backend):
     t1 = time.perf_counter()
 
     ms = (t1 - t0) * 1e3 / args.steps
-    if world > 1:
+    if dist is not None:
         tt = torch.tensor([ms], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         ms = float(tt.item())
@@ -438,7 +438,7 @@ def run_interp7(args, rank, world, device, dist, backend):
                 n, H, W, H, W, -2, -2, 0, args.radius, stream), "head_forward")
 
     def barrier():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -456,7 +456,7 @@ def run_interp7(args, rank, world, device, dist, backend):
     barrier()
     t1 = time.perf_counter()
     ms = (t1 - t0) * 1e3 / args.steps
-    if world > 1:
+    if dist is not None:
         tt = torch.tensor([ms], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         ms = float(tt.item())
@@ -520,7 +520,9 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    # BENCH_FORCE_DIST=1: initialise the process group for a single rank too (rehearses the RCCL
+    # init / barrier / all-reduce calls on a one-GPU box; launch under torch.distributed.run)
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
@@ -531,7 +533,7 @@ def main():
     line = run(args, rank, world, device, dist, backend)
     if rank == 0:
         print(json.dumps(line))
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
