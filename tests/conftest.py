@@ -81,15 +81,24 @@ def make_operands(N, C, H, W, k=5, d=1, regime="gauss1", seed=0, weights="softma
 # 3.0e-7 * max|oracle| over every GPU test (profiles/parity_errors.txt) -- whatever the size of the
 # element itself.  An elementwise relative bound of rtol can therefore only be asked of elements
 # of at least ~5e-7 / rtol of the tensor's scale: 0.05 * max for the forward's 1e-5, 0.005 * max for
-# the backward's 1e-4; smaller elements are cancelling sums whose error (1) bounds in absolute
-# terms.  The worst elementwise error on the wider set |oracle| >= 1e-3 * max is recorded too.
+# the backward's 1e-4 (0.2 * max for gradInput, see elem_floor); smaller elements are cancelling sums
+# whose error (1) bounds in absolute terms.  The worst elementwise error on the wider set |oracle| >= 1e-3 * max is recorded too.
 # Worst observed errors are printed in the terminal summary and written to
 # gpurun_out/parity_errors.txt (tracked copy: profiles/parity_errors.txt).
 WIDE_FLOOR_FRAC = 1e-3
 ELEM_ASSERT = os.environ.get("PARITY_ELEMWISE", "assert") != "record"
 
 
-def elem_floor(rtol):
+def elem_floor(rtol, what=""):
+    # gradInput (no reference counterpart) is an adjoint scatter: a texel sums up to thousands of
+    # signed contributions (every tap clamped onto a border texel), in fp32 atomics whose order
+    # differs run to run (mode ATOMIC) or on a fixed-point grid that is absolute, not relative
+    # (mode DETERMINISTIC).  Its error is a few 1e-6 .. 2e-5 of the tensor's scale (norm_rel column
+    # of profiles/parity_errors.txt), not 3e-7, so rtol can only be asked elementwise of elements of
+    # at least 2e-5 / rtol of the scale -- and in mode ATOMIC a tighter floor would make the assert
+    # depend on the run (seen once: 1.15e-4 on an element of 0.5 % of the scale).
+    if "grad_input" in what:
+        return min(0.5, 2e-5 / rtol)
     return min(0.5, 5e-7 / rtol)
 
 
@@ -126,7 +135,7 @@ def parity_close(actual, desired, rtol, what="", floor=1e-30, elementwise=True):
         big = d >= frac * ref
         return float((err[big] / d[big]).max()) if big.any() else 0.0
 
-    elem_rel, wide_rel = worst(elem_floor(rtol)), worst(WIDE_FLOOR_FRAC)
+    elem_rel, wide_rel = worst(elem_floor(rtol, what)), worst(WIDE_FLOOR_FRAC)
     name = (what.split(",")[0].strip() or "tensor")
     rec = _parity_worst.setdefault((_caller_module(), name, rtol), [0.0, 0.0, 0.0, 0])
     rec[0] = max(rec[0], norm_rel)
@@ -136,14 +145,14 @@ def parity_close(actual, desired, rtol, what="", floor=1e-30, elementwise=True):
     if elementwise and ELEM_ASSERT:
         assert elem_rel <= rtol, (
             f"{what}: worst elementwise relative error {elem_rel:.3e} on elements >= "
-            f"{elem_floor(rtol):g} * max|oracle| exceeds {rtol:g}")
+            f"{elem_floor(rtol, what):g} * max|oracle| exceeds {rtol:g}")
 
 
 def _parity_report_lines():
     lines = ["# worst observed parity errors (HIP vs oracle; oracle vs its second restatement in the "
              "CPU tests), per test module and tensor",
              "# norm_rel = max|a-b| / max|b| ; elem_rel = max |a-b|/|b| over elements with |b| >= "
-             "(5e-7/rtol) * max|b| (asserted <= rtol) ; wide_rel = the same over |b| >= %g * max|b| "
+             "(5e-7/rtol) * max|b| -- gradInput: (2e-5/rtol) -- (asserted <= rtol) ; wide_rel = the same over |b| >= %g * max|b| "
              "(recorded)" % WIDE_FLOOR_FRAC,
              "%-26s %-30s %6s %10s %10s %10s %6s" % ("module", "tensor", "rtol", "norm_rel",
                                                      "elem_rel", "wide_rel", "checks")]
