@@ -651,6 +651,7 @@ __device__ __forceinline__ Centre tile_centre(const float *__restrict__ ab,
 #endif
 constexpr int kMaxPasses = SYNTH_MAX_PASSES;
 constexpr int kPassMinPixels = SYNTH_PASS_MIN_PIXELS;  // pixels with unserved taps that justify a pass
+constexpr int kPassDepth = 3;                          // taps in flight in a further pass of the backward
 constexpr int kVoteSlots = 4;                          // floats of LDS per wave for the vote
 constexpr float kNoCentre = 1.0e30f;                   // a window that serves nothing
 
@@ -1606,11 +1607,25 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
         auto run_taps = [&](auto first_tag, const Centre ctr) {
             constexpr bool FIRST = decltype(first_tag)::value != 0;
             const int cbase = (((int)ctr.y) * LW + (int)ctr.x) * 16;  // the window's shift
+            // Taps in flight ahead of the one being computed.  First pass: one -- every CU streams
+            // at once and the HBM is the limit.  A further pass runs on a few CUs while the others
+            // saturate the memory, and with one tap ahead it exposes most of a ~1.7 us round trip per
+            // tap (tools/tile_clock.py: 23-26 us per pass, 8 of them VALU): kPassDepth ahead there
+            // (steep smooth flow: 507 -> 495 us; the forward's 256 registers -- two waves per SIMD --
+            // hold no more than one).
+            constexpr int D = FIRST ? 1 : kPassDepth;
+            TapCol<ROWS> ahead[D > 1 ? D - 1 : 1];
+            if constexpr (D > 1) {
+                static_for<1, D>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    load_tap_col<ROWS>(ahead[i - 1], wb, ab, bb, pl, i, rf, (unsigned)x);
+                });
+            }
             static_for<0, 25>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
                 constexpr int r = t / 5, s = t % 5;
                 TapCol<ROWS> nxt;
-                if (t < 24) load_tap_col<ROWS>(nxt, wb, ab, bb, pl, t + 1, rf, (unsigned)x);
+                if (t + D < 25) load_tap_col<ROWS>(nxt, wb, ab, bb, pl, t + D, rf, (unsigned)x);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < ROWS; ++j) {
@@ -1657,7 +1672,14 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
                     if (j % kRowGroup == kRowGroup - 1) __builtin_amdgcn_sched_barrier(0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                cur = nxt;
+                if constexpr (D == 1) {
+                    cur = nxt;
+                } else {
+                    cur = ahead[0];
+#pragma unroll
+                    for (int i = 0; i + 2 < D; ++i) ahead[i] = ahead[i + 1];
+                    ahead[D - 2] = nxt;
+                }
             });
         };
 

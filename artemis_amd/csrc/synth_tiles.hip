@@ -67,7 +67,10 @@ struct TileCfg {
 #endif
 template <int R>
 struct BwdCfg {
-    static constexpr int WAVES = SYNTH_BWD_WAVES, WX = SYNTH_WX, ROWS = SYNTH_BWD_ROWS, OCC = 2,
+    // OCC 1: one workgroup of 4 waves per CU (kSolo) is one wave per SIMD, so the kernel may use the
+    // whole 512-register file; with 2 the compiler held the small radii (whose LDS would admit a
+    // second workgroup) to 256 registers and spilled 60-240 of them
+    static constexpr int WAVES = SYNTH_BWD_WAVES, WX = SYNTH_WX, ROWS = SYNTH_BWD_ROWS, OCC = 1,
                          NWIN = SYNTH_NWIN;
     static constexpr bool kSolo = true;
 };
