@@ -44,6 +44,28 @@ def shard_items(batch: int, timesteps: int, rank: int, world: int) -> List[WorkI
     return [WorkItem(i // timesteps, i % timesteps) for i in range(b, e)]
 
 
+@dataclass(frozen=True)
+class InterpolationShard:
+    timesteps: Tuple[int, ...]  # indices into the list of output times this rank computes ...
+    y0: int                     # ... for output rows [y0, y1) of the frame
+    y1: int
+
+
+def shard_interpolation(timesteps: int, height: int, rank: int, world: int) -> InterpolationShard:
+    """Interpolate mode for ONE window (BASELINE.json configs[3]: 7 timesteps of a 1080p window).
+    When the ranks divide the timesteps, every rank takes whole frames (`shard_items`).  Otherwise
+    dealing whole timesteps leaves ranks idle -- 7 timesteps on 2, 4 or 8 GPUs: the busiest rank
+    holds 4/7, 2/7, 1/7 of the work, 87.5 % efficiency at best -- so every rank takes a row strip of
+    ALL timesteps instead: one launch of N = timesteps over rows [y0, y1), addressed through the
+    explicit frame geometry (org_y = y0 - pad; the frames stay whole, weights / offsets / occlusion
+    exist for the strip only).  Still no collective: the op is pointwise in its output pixel."""
+    if timesteps % world == 0:
+        b, e = shard_bounds(timesteps, rank, world)
+        return InterpolationShard(tuple(range(b, e)), 0, height)
+    y0, y1 = shard_bounds(height, rank, world)
+    return InterpolationShard(tuple(range(timesteps)), y0, y1)
+
+
 def shard_batch(tensors: Sequence, rank: int, world: int):
     """Slice dim 0 of each tensor to this rank's samples (views, no copy)."""
     n = tensors[0].shape[0]

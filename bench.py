@@ -415,27 +415,35 @@ def run_train(args, rank, world, device, dist, backend):
 
 def run_interp7(args, rank, world, device, dist, backend):
     """BASELINE.json configs[3]: interpolate mode, one 4-frame 1080p window, 7 timesteps
-    (main.py:114-121 runs them one model forward at a time).  Timesteps are dealt with
-    sharding.shard_items; a rank runs all of ITS timesteps as one fused-head forward launch."""
-    from artemis_amd.sharding import shard_items
+    (main.py:114-121 runs them one model forward at a time).  sharding.shard_interpolation deals
+    whole timesteps when the ranks divide 7 and a row strip of all 7 otherwise (--interp-shard
+    timesteps forces whole timesteps: 7 busy ranks + 1 idle on 8 GPUs); a rank runs ITS share as
+    one fused-head forward launch."""
+    from artemis_amd.sharding import InterpolationShard, shard_interpolation, shard_items
     lib = _lib.load()
     stream = torch.cuda.current_stream().cuda_stream
     TS = 7
-    items = shard_items(1, TS, rank, world)
-    n = len(items)
+    if args.interp_shard == "timesteps":
+        sh = InterpolationShard(tuple(i.timestep for i in shard_items(1, TS, rank, world)), 0, H)
+    else:
+        sh = shard_interpolation(TS, H, rank, world)
+    n, Hl = len(sh.timesteps), sh.y1 - sh.y0
     T = FRAMES
-    if n:
-        # the window's 4 frames are the same for every timestep; weights/offsets/occlusion differ
+    if n and Hl:
+        # the window's 4 frames are the same for every timestep and stay whole; weights / offsets /
+        # occlusion differ per timestep and exist for this rank's rows only
         frames1, w, a, b, occ, _ = head_operands(n, device, f"sigma:{args.sigma}", 300 + rank)
         frames = [f[:1].expand(n, C, H, W).contiguous() for f in frames1]
-        out = torch.empty(n, C, H, W, device=device)
+        w, a, b = (t[:, :, :, :Hl].contiguous() for t in (w, a, b))
+        occ = occ[:, :, :Hl].contiguous()
+        out = torch.empty(n, C, Hl, W, device=device)
         ptrs = (ctypes.c_void_p * T)(*[f.data_ptr() for f in frames])
 
     def step():
-        if n:
+        if n and Hl:
             _lib.check(lib.artemis_synth_head_forward(
                 ptrs, T, w.data_ptr(), a.data_ptr(), b.data_ptr(), occ.data_ptr(), out.data_ptr(),
-                n, H, W, H, W, -2, -2, 0, args.radius, stream), "head_forward")
+                n, Hl, W, H, W, sh.y0 - 2, -2, 0, args.radius, stream), "head_forward")
 
     def barrier():
         if dist is not None:
@@ -464,8 +472,8 @@ def run_interp7(args, rank, world, device, dist, backend):
         return None
     kernel_ms = e0.elapsed_time(e1) / args.steps
     value = TS * H * W / (ms * 1e-3) / 1e6
-    gbs = HEAD_FWD_BYTES * n * H * W / (kernel_ms * 1e-3) / 1e9
-    busy = min(world, TS)
+    gbs = HEAD_FWD_BYTES * n * Hl * W / (kernel_ms * 1e-3) / 1e9
+    busy = world if sh.y1 - sh.y0 < H else min(world, TS)
     return {
         "metric": "synthesized Mpix/s fwd (interpolate: 7 timesteps, 4 frames, 1080p)",
         "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
@@ -474,16 +482,19 @@ def run_interp7(args, rank, world, device, dist, backend):
         "config": {
             "workload": "interp7: fused ChronoSynth head forward, one 4-frame 1080x1920 window, 7 "
                         "timesteps (BASELINE.json configs[3]), k=5 d=1 C=3, fp32",
-            "timesteps_on_rank0": n, "busy_ranks": busy, "idle_ranks": world - busy,
+            "timesteps_on_rank0": n, "rows_on_rank0": [sh.y0, sh.y1], "busy_ranks": busy,
+            "idle_ranks": world - busy,
             "offset_regime": f"sigma:{args.sigma:g}", "tile_radius": args.radius,
-            "sharding": "sharding.shard_items(1, 7, rank, world): timesteps dealt in balanced "
-                        "blocks, no collective",
+            "sharding": ("sharding.shard_items(1, 7, rank, world): whole timesteps in balanced blocks"
+                         if args.interp_shard == "timesteps" else
+                         "sharding.shard_interpolation(7, 1080, rank, world): whole timesteps when the "
+                         "ranks divide 7, else a row strip of all 7 per rank") + ", no collective",
         },
         "roofline": {
             "kernel": "synth_fwd_tapmajor<HEAD> (fused 4-frame head forward), rank 0's launch",
             "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
-            "algorithmic_bytes_per_launch": round(HEAD_FWD_BYTES * n * H * W),
+            "algorithmic_bytes_per_launch": round(HEAD_FWD_BYTES * n * Hl * W),
             "avg_launch_ms": round(kernel_ms, 4),
         },
     }
@@ -496,6 +507,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=["train", "interp7"], default="train",
                     help="train = the headline (op fwd+bwd, 4 frames, 1080p); interp7 = configs[3]")
+    ap.add_argument("--interp-shard", choices=["auto", "timesteps"], default="auto",
+                    help="interp7 on N ranks: auto = sharding.shard_interpolation (row strips of all "
+                         "timesteps when N does not divide 7); timesteps = whole timesteps only")
     ap.add_argument("--batch", type=int, default=1, help="samples per GPU (1080p each)")
     ap.add_argument("--sigma", type=float, default=1.0, help="offset std in pixels (headline: 1)")
     ap.add_argument("--radius", type=int, default=-1,

@@ -75,6 +75,15 @@ def test_rccl_calls_with_one_forced_rank():
     check_line(d, 1)
 
 
+def test_interp7_two_ranks_take_row_strips_of_all_timesteps():
+    d = run_bench(["--workload", "interp7", "--steps", "2", "--warmup", "1", "--gpus", "2", "--no-cpu-baseline"],
+                  nproc=2, env={"BENCH_DIST_BACKEND": "gloo"})
+    check_line(d, 2)
+    c = d["config"]
+    assert c["timesteps_on_rank0"] == 7 and c["rows_on_rank0"] == [0, 540] and c["idle_ranks"] == 0
+    assert abs(d["value"] - 7 * 1080 * 1920 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-3
+
+
 def test_interp7_workload():
     d = run_bench(["--workload", "interp7", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
     check_line(d, 1)

@@ -46,6 +46,60 @@ def test_interpolate_config_7_timesteps_on_8_gpus():
     assert all(len(sharding.shard_items(64, 1, r, 8)) == 8 for r in range(8))
 
 
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 7, 8, 14])
+def test_interpolation_shards_cover_every_pixel_of_every_timestep_once(world):
+    TS, Hh = 7, 1080
+    seen = np.zeros((TS, Hh), np.int32)
+    loads = []
+    for r in range(world):
+        sh = sharding.shard_interpolation(TS, Hh, r, world)
+        for t in sh.timesteps:
+            seen[t, sh.y0:sh.y1] += 1
+        loads.append(len(sh.timesteps) * (sh.y1 - sh.y0))
+    assert (seen == 1).all()
+    # whole timesteps when the ranks divide them, else a row strip of all of them: balanced to a row
+    if TS % world == 0:
+        assert all(sharding.shard_interpolation(TS, Hh, r, world).y1 == Hh for r in range(world))
+    assert max(loads) - min(loads) <= TS
+    assert max(loads) * world <= TS * Hh * 1.01 + TS * world      # >= 99 % balanced at 1080 rows
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 8])
+def test_interpolation_row_strips_reproduce_the_whole_frame_on_gpu(world):
+    """The strips of sharding.shard_interpolation through the fused head's frame geometry: the
+    ranks' outputs, stacked, are the single-launch result bit for bit (offsets within the window)."""
+    import ctypes
+    from artemis_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(5)
+    TS, T, Hh, Ww = 7, 4, 150, 200
+    frames = [torch.rand(1, 3, Hh, Ww, device=dev, generator=g).expand(TS, 3, Hh, Ww).contiguous() for _ in range(T)]
+    w = torch.softmax(torch.randn(TS, T, 25, Hh, Ww, device=dev, generator=g), 2)
+    a, b = (torch.randn(TS, T, 25, Hh, Ww, device=dev, generator=g) * 1.5 for _ in range(2))
+    occ = torch.softmax(torch.randn(TS, T, Hh, Ww, device=dev, generator=g), 1)
+    ptrs = (ctypes.c_void_p * T)(*[f.data_ptr() for f in frames])
+    st = torch.cuda.current_stream().cuda_stream
+
+    def head(wt, at, bt, ot, n, rows, y0):
+        out = torch.empty(n, 3, rows, Ww, device=dev)
+        _lib.check(lib.artemis_synth_head_forward(ptrs, T, wt.data_ptr(), at.data_ptr(), bt.data_ptr(), ot.data_ptr(),
+                                                  out.data_ptr(), n, rows, Ww, Hh, Ww, y0 - 2, -2, 0, -1, st), "head")
+        return out
+
+    full = head(w, a, b, occ, TS, Hh, 0)
+    parts = []
+    for r in range(world):
+        sh = sharding.shard_interpolation(TS, Hh, r, world)
+        assert sh.timesteps == tuple(range(TS))
+        sl = slice(sh.y0, sh.y1)
+        parts.append(head(w[:, :, :, sl].contiguous(), a[:, :, :, sl].contiguous(), b[:, :, :, sl].contiguous(),
+                          occ[:, :, sl].contiguous(), TS, sh.y1 - sh.y0, sh.y0))
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat(parts, 2), full)
+
+
 def test_row_strips_cover_frame():
     strips = sharding.row_strips(2160, 8, halo=9)
     assert strips[0][0] == 0 and strips[-1][1] == 2160
