@@ -3,6 +3,7 @@
 synth_device.hpp): how long each workgroup holds its CU, how many windows it staged and how many
 pixels it left to the per-pixel fix-up -- to see what a launch waits for in a given offset regime.
 
+    tools/build_variants.sh clock:-DSYNTH_DEV_TILE_CLOCK        # -> artemis_amd/lib/exp/libsynth_clock.so
     python tools/tile_clock.py artemis_amd/lib/exp/libsynth_clock.so --regime smooth30
 """
 import argparse
