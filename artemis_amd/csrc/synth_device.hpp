@@ -1139,9 +1139,10 @@ __device__ __forceinline__ void load_tap_col(TapCol<ROWS> &t, const float *__res
 // before the first LDS write: left to itself hipcc waits vmcnt(0) after every texel, which
 // serialises ~14 L2 round trips (~10 us) at the head of every workgroup.  The batch size balances
 // the rounds: as few rounds as batches of at most kFillBatchMax allow, all of about the same size
-// (R = 8: one round of 13 texels per lane; R = 14: two of 10).
+// (forward, 256 lanes per window: R = 8 one round of 13 texels per lane, R = 14 one of 19 -- two
+// rounds of 10 cost the forward 1.5 %; backward, 128 lanes per window: R = 14 two rounds of 19).
 #ifndef SYNTH_FILL_BATCH
-#define SYNTH_FILL_BATCH 13
+#define SYNTH_FILL_BATCH 19
 #endif
 constexpr int kFillBatchMax = SYNTH_FILL_BATCH;
 
