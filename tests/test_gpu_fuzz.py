@@ -1,5 +1,7 @@
 """Randomised GPU parity: seeded random shapes, regimes, radii, gradient subsets and frame
 geometries against the CPU oracle; empty problems through the operator."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -28,7 +30,7 @@ def close(actual, desired, rtol, what="", floor=1e-30):
 REGIMES = ["init", "gauss1", "gauss4", "uniform3", "clamp40", "integer", "zero"]
 
 
-@pytest.mark.parametrize("case", range(40))
+@pytest.mark.parametrize("case", range(int(os.environ.get("FUZZ_CASES", "40"))))
 def test_random_case_against_oracle(dev, oracle, case):
     import artemis_amd
     rng = np.random.default_rng(9000 + case)
@@ -125,7 +127,8 @@ def random_motion_field(rng, N, H, W):
     return oy, ox
 
 
-@pytest.mark.parametrize("case", range(24))
+# (FUZZ_MOTION_CASES / FUZZ_CASES: longer one-off soaks, e.g. 600 each after a change to the windows)
+@pytest.mark.parametrize("case", range(int(os.environ.get("FUZZ_MOTION_CASES", "24"))))
 def test_random_motion_fields_against_oracle(dev, oracle, case):
     """The window-following machinery (first centres, votes, further windows, the three fix-up
     forms) on random piecewise-coherent motion, op and fused head, both tile shapes."""
