@@ -200,3 +200,28 @@ def test_config4_4k_bf16_strip_against_oracle(dev, fast_oracle, strip):
     parity_close(w.grad, rgw, BWD_RTOL, "config4 strip grad_weight")
     parity_close(oy.grad, rga, BWD_RTOL, "config4 strip grad_offset_y", term)
     parity_close(ox.grad, rgb, BWD_RTOL, "config4 strip grad_offset_x", term)
+
+
+# ------------------------------------------------------------------ the bench's other offset regimes
+@pytest.mark.parametrize("regime", ["smooth30", "sigma:4", "pan"])
+def test_bench_regimes_at_1080p_against_oracle(dev, fast_oracle, regime):
+    """The offset regimes bench.py times beside the headline (config.other_offset_regimes), one
+    1080p frame each at the default radius, forward and backward against the oracle: smooth30 is
+    where tiles stage two and three windows."""
+    import os
+    import sys
+    import artemis_amd
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    f = bench.make_frames(1, 1.0, dev, 11, regime=regime)[0]
+    t = [f["inp"]] + [f[k].clone().requires_grad_(True) for k in ("w", "oy", "ox")]
+    out = artemis_amd.FunctionSynth.apply(*t, 1)
+    out.backward(f["gout"])
+    torch.cuda.synchronize()
+    inp, w, oy, ox, gout = (np_(f[k]) for k in ("inp", "w", "oy", "ox", "gout"))
+    parity_close(out, fast_oracle.forward(inp, w, oy, ox, 1), FWD_RTOL, f"{regime} 1080p output")
+    _, rgw, rga, rgb = fast_oracle.backward(gout, inp, w, oy, ox, 1, with_input=False)
+    term = float(np.abs(gout).max() * np.abs(w).max() * np.abs(inp).max())
+    parity_close(t[1].grad, rgw, BWD_RTOL, f"{regime} 1080p grad_weight")
+    parity_close(t[2].grad, rga, BWD_RTOL, f"{regime} 1080p grad_offset_y", floor=term)
+    parity_close(t[3].grad, rgb, BWD_RTOL, f"{regime} 1080p grad_offset_x", floor=term)
