@@ -10,7 +10,7 @@ CSRC = os.path.join(_PKG, "csrc")
 SRC = os.path.join(CSRC, "synth_kernels.hip")        # C ABI, host logic, direct kernels
 TILES_SRC = os.path.join(CSRC, "synth_tiles.hip")     # LDS-staged kernels, one object per radius
 DEVICE_HDR = os.path.join(CSRC, "synth_device.hpp")
-TILE_RADII = (2, 4, 8, 14)
+TILE_RADII = (2, 4, 8, 14, 24)
 INCLUDE = os.path.join(_ROOT, "include")
 LIB_DIR = os.path.join(_PKG, "lib")
 OBJ_DIR = os.path.join(LIB_DIR, "obj")

@@ -92,7 +92,15 @@ int pick_radius(int requested)
     if (requested <= 2) return 2;
     if (requested <= 4) return 4;
     if (requested <= 8) return 8;
-    return 14;
+    if (requested <= 14) return 14;
+    return 24;
+}
+
+// gradInput's 64-bit accumulator window does not fit the LDS beyond R = 14
+int gin_radius(int requested)
+{
+    const int R = pick_radius(requested);
+    return R > 14 ? 14 : R;
 }
 
 bool tiled_ok(const Geom &g) { return g.k == 5 && g.d == 1 && g.C == 3; }
@@ -163,6 +171,7 @@ void dispatch_fwd_tiled(int R, const void *input, const float *weight, const flo
     case 2: launch_fwd_tiled<2, FT>(in, weight, offset_y, offset_x, output, g, st); break;
     case 4: launch_fwd_tiled<4, FT>(in, weight, offset_y, offset_x, output, g, st); break;
     case 8: launch_fwd_tiled<8, FT>(in, weight, offset_y, offset_x, output, g, st); break;
+    case 24: launch_fwd_tiled<24, FT>(in, weight, offset_y, offset_x, output, g, st); break;
     default: launch_fwd_tiled<14, FT>(in, weight, offset_y, offset_x, output, g, st); break;
     }
 }
@@ -177,6 +186,7 @@ void dispatch_bwd_tiled(int R, const void *input, const float *weight, const flo
     case 2: launch_bwd_tiled<2, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, st); break;
     case 4: launch_bwd_tiled<4, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, st); break;
     case 8: launch_bwd_tiled<8, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, st); break;
+    case 24: launch_bwd_tiled<24, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, st); break;
     default: launch_bwd_tiled<14, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, st); break;
     }
 }
@@ -189,6 +199,7 @@ void dispatch_head_fwd(int R, const float *w, const float *oy, const float *ox, 
     case 2: launch_head_fwd<2, FT>(w, oy, ox, out, g, ha, st); break;
     case 4: launch_head_fwd<4, FT>(w, oy, ox, out, g, ha, st); break;
     case 8: launch_head_fwd<8, FT>(w, oy, ox, out, g, ha, st); break;
+    case 24: launch_head_fwd<24, FT>(w, oy, ox, out, g, ha, st); break;
     default: launch_head_fwd<14, FT>(w, oy, ox, out, g, ha, st); break;
     }
 }
@@ -202,6 +213,7 @@ void dispatch_head_bwd(int R, const float *w, const float *oy, const float *ox,
     case 2: launch_head_bwd<2, FT>(w, oy, ox, gout, gw, goy, gox, g, ha, st); break;
     case 4: launch_head_bwd<4, FT>(w, oy, ox, gout, gw, goy, gox, g, ha, st); break;
     case 8: launch_head_bwd<8, FT>(w, oy, ox, gout, gw, goy, gox, g, ha, st); break;
+    case 24: launch_head_bwd<24, FT>(w, oy, ox, gout, gw, goy, gox, g, ha, st); break;
     default: launch_head_bwd<14, FT>(w, oy, ox, gout, gw, goy, gox, g, ha, st); break;
     }
 }
@@ -332,7 +344,7 @@ static int run_backward(const Geom &g, int rc, const void *input_any, const floa
     }
 
     if (grad_input) {
-        const int Rg = tiled_ok(g) ? pick_radius(tile_radius) : 0;
+        const int Rg = tiled_ok(g) ? gin_radius(tile_radius) : 0;
         const int bits = count_bits_for(g);
         const bool fixed = gin_mode == ARTEMIS_SYNTH_GIN_DETERMINISTIC;
         const size_t need = ws_bytes_needed(g, gin_mode, Rg);

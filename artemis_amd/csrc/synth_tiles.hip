@@ -1,4 +1,4 @@
-// synth_tiles.hip -- the LDS-staged kernels for ONE tile radius (-DSYNTH_TILE_R=2|4|8|14):
+// synth_tiles.hip -- the LDS-staged kernels for ONE tile radius (-DSYNTH_TILE_R=2|4|8|14|24):
 // explicit instantiations of the launchers declared in synth_device.hpp.  One object per radius
 // lets the heavily unrolled tap-major kernels compile in parallel.
 #include "synth_device.hpp"
@@ -73,6 +73,22 @@ struct BwdCfg {
     static constexpr int WAVES = SYNTH_BWD_WAVES, WX = SYNTH_WX, ROWS = SYNTH_BWD_ROWS, OCC = 1,
                          NWIN = SYNTH_NWIN;
     static constexpr bool kSolo = true;
+};
+
+// Radius 24 (callers who know their offsets are large: tile_radius > 14): one window of
+// (16 + 5 + 48) x (64 + 5 + 48) texels = 129 KB serves a 64 x 16 tile -- half the plane-row length of
+// the default shape (1080p, sigma = 1: 141 / 268 us against 118 / 249), three times the displacement
+// area of R = 14 (steep smooth +-30 px flow: 162 / 306 us against 256 / 504; sigma = 16: 766 / 1776
+// against 1312 / 1962).
+template <>
+struct TileCfg<24> {
+    static constexpr int WAVES = 8, WX = 1, ROWS = 2, OCC = 2, NWIN = 1;
+    static constexpr bool kSolo = false;
+};
+template <>
+struct BwdCfg<24> {
+    static constexpr int WAVES = 4, WX = 1, ROWS = 4, OCC = 1, NWIN = 1;
+    static constexpr bool kSolo = false;
 };
 
 struct SmallCfg {
@@ -223,7 +239,7 @@ template void launch_head_fwd<SYNTH_TILE_R, frame_t>(const float *, const float 
 template void launch_head_bwd<SYNTH_TILE_R, frame_t>(const float *, const float *, const float *,
                                                      const float *, float *, float *, float *,
                                                      const Geom &, const HeadArgs &, hipStream_t);
-#if !SYNTH_TILE_BF16
+#if !SYNTH_TILE_BF16 && SYNTH_TILE_R <= 14  // (gradInput's 64-bit accumulator window tops out at R = 14)
 template void launch_gin_tiled<SYNTH_TILE_R, false>(const float *, const float *, const float *,
                                                     const float *, float *, unsigned char *,
                                                     const Geom &, int, hipStream_t);

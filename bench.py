@@ -303,7 +303,11 @@ class Op:
 
 
 def regime_timing(lib, device, B, radius, stream, regime, steps, headline_mpix):
-    """The same step under another offset regime (few steps, HIP events)."""
+    """The same step under another offset regime (few steps, HIP events).  '<regime>@<r>' runs it
+    at tile radius r instead of the headline's."""
+    if "@" in regime:
+        regime, r = regime.split("@")
+        radius = int(r)
     frames = make_frames(B, 0.0, device, seed=211, regime=regime)
     op = Op(lib, frames, B, radius, stream)
     for _ in range(2):
@@ -514,8 +518,9 @@ def main():
     ap.add_argument("--sigma", type=float, default=1.0, help="offset std in pixels (headline: 1)")
     ap.add_argument("--radius", type=int, default=-1,
                     help="LDS tile radius passed to the library; -1 = the library default")
-    ap.add_argument("--regimes", default="smooth30,sigma:4",
-                    help="other offset regimes timed beside the headline at N = 1 ('' = none)")
+    ap.add_argument("--regimes", default="smooth30,sigma:4,smooth30@24",
+                    help="other offset regimes timed beside the headline at N = 1 ('' = none); "
+                         "'<regime>@<r>' = at tile radius r (24: the shape for large steep offsets)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, host cpus)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-head", action="store_true", help="skip the fused-head side measurement")
