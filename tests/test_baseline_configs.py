@@ -203,11 +203,12 @@ def test_config4_4k_bf16_strip_against_oracle(dev, fast_oracle, strip):
 
 
 # ------------------------------------------------------------------ the bench's other offset regimes
-@pytest.mark.parametrize("regime", ["smooth30", "sigma:4", "pan"])
-def test_bench_regimes_at_1080p_against_oracle(dev, fast_oracle, regime):
+@pytest.mark.parametrize("regime,radius", [("smooth30", -1), ("sigma:4", -1), ("pan", -1), ("smooth30", 24),
+                                           ("sigma:8", 24)])
+def test_bench_regimes_at_1080p_against_oracle(dev, fast_oracle, regime, radius):
     """The offset regimes bench.py times beside the headline (config.other_offset_regimes), one
-    1080p frame each at the default radius, forward and backward against the oracle: smooth30 is
-    where tiles stage two and three windows."""
+    1080p frame each at the default radius (and the steep / scattered ones at radius 24), forward and
+    backward against the oracle: smooth30 is where tiles stage two and three windows."""
     import os
     import sys
     import artemis_amd
@@ -215,9 +216,11 @@ def test_bench_regimes_at_1080p_against_oracle(dev, fast_oracle, regime):
     import bench
     f = bench.make_frames(1, 1.0, dev, 11, regime=regime)[0]
     t = [f["inp"]] + [f[k].clone().requires_grad_(True) for k in ("w", "oy", "ox")]
-    out = artemis_amd.FunctionSynth.apply(*t, 1)
-    out.backward(f["gout"])
+    with artemis_amd.synth_options(tile_radius=radius):
+        out = artemis_amd.FunctionSynth.apply(*t, 1)
+        out.backward(f["gout"])
     torch.cuda.synchronize()
+    regime = f"{regime} R{radius}"
     inp, w, oy, ox, gout = (np_(f[k]) for k in ("inp", "w", "oy", "ox", "gout"))
     parity_close(out, fast_oracle.forward(inp, w, oy, ox, 1), FWD_RTOL, f"{regime} 1080p output")
     _, rgw, rga, rgb = fast_oracle.backward(gout, inp, w, oy, ox, 1, with_input=False)
