@@ -75,19 +75,21 @@ struct BwdCfg {
     static constexpr bool kSolo = true;
 };
 
-// Radius 24 (callers who know their offsets are large: tile_radius > 14): one window of
-// (16 + 5 + 48) x (64 + 5 + 48) texels = 129 KB serves a 64 x 16 tile -- half the plane-row length of
-// the default shape (1080p, sigma = 1: 141 / 268 us against 118 / 249), three times the displacement
-// area of R = 14 (steep smooth +-30 px flow: 162 / 306 us against 256 / 504; sigma = 16: 766 / 1776
-// against 1312 / 1962).
+// Radius 24 (tile_radius > 14, for callers whose offsets are large): one window of
+// (32 + 5 + 48) x (64 + 5 + 48) texels = 159 KB serves a 64 x 32 tile, 8 waves x 4 rows in both
+// directions -- half the plane-row length of the default shape, three times its displacement area.
+// 1080p forward / backward us: sigma = 1 118 / 257 (default shape 116 / 246), sigma = 4 118 / 257
+// (131 / 268), steep smooth +-30 px flow 148 / 300 (242 / 498), sigma = 16 731 / 1653 (1305 / 1960).
+// (64 x 16 tiles with this window: 141 / 266 at sigma = 1; the backward as 4 waves x 8 rows: 314 on the
+// steep flow.)
 template <>
 struct TileCfg<24> {
-    static constexpr int WAVES = 8, WX = 1, ROWS = 2, OCC = 2, NWIN = 1;
+    static constexpr int WAVES = 8, WX = 1, ROWS = 4, OCC = 2, NWIN = 1;
     static constexpr bool kSolo = false;
 };
 template <>
 struct BwdCfg<24> {
-    static constexpr int WAVES = 4, WX = 1, ROWS = 4, OCC = 1, NWIN = 1;
+    static constexpr int WAVES = 8, WX = 1, ROWS = 4, OCC = 2, NWIN = 1;
     static constexpr bool kSolo = false;
 };
 

@@ -518,7 +518,7 @@ def main():
     ap.add_argument("--sigma", type=float, default=1.0, help="offset std in pixels (headline: 1)")
     ap.add_argument("--radius", type=int, default=-1,
                     help="LDS tile radius passed to the library; -1 = the library default")
-    ap.add_argument("--regimes", default="smooth30,sigma:4,smooth30@24",
+    ap.add_argument("--regimes", default="smooth30,sigma:4,smooth30@24,sigma:1@24",
                     help="other offset regimes timed beside the headline at N = 1 ('' = none); "
                          "'<regime>@<r>' = at tile radius r (24: the shape for large steep offsets)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, host cpus)")

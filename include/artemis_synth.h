@@ -51,10 +51,10 @@ extern "C" {
  * those -- so large coherent motion runs from LDS whatever its size.  > 0 picks the smallest built
  * radius (2, 4, 8, 14, 24) that covers it, 24 beyond; ARTEMIS_SYNTH_RADIUS_DEFAULT lets the library
  * choose (14); ARTEMIS_SYNTH_RADIUS_NONE disables LDS staging (direct gathers through L1/L2).
- * Radius 24 is for callers who know their offsets are large or steep (a flow that changes by tens
- * of pixels across a tile, independent displacements of 5-10 px per tap): one window per 64 x 16
- * tile instead of two per 128 x 16, which costs 10-20 % when the offsets are small and wins up to
- * 1.6x when they are not (grad_input's accumulator window stays at 14).  Only k = 5,
+ * Radius 24 is for offsets that may be large or steep (a flow that changes by tens of pixels across
+ * a tile, independent displacements of 4-10 px per tap): one window per 64 x 32 tile instead of two
+ * per 128 x 16, which costs 3-4 % when the offsets are small and wins 8-60 % when they are not
+ * (grad_input's accumulator window stays at 14).  Only k = 5,
  * d = 1, C = 3 (the model's configuration: config.py:26-27) has an LDS-staged kernel; other shapes
  * always gather directly. */
 #define ARTEMIS_SYNTH_RADIUS_DEFAULT (-1)
