@@ -11,6 +11,7 @@ SRC = os.path.join(CSRC, "synth_kernels.hip")        # C ABI, host logic, direct
 TILES_SRC = os.path.join(CSRC, "synth_tiles.hip")     # LDS-staged kernels, one object per radius
 DEVICE_HDR = os.path.join(CSRC, "synth_device.hpp")
 TILE_RADII = (2, 4, 8, 14, 24)
+BF16_RADII = (8, 14, 24)       # bf16 frames: smaller requests run the radius-8 kernels
 INCLUDE = os.path.join(_ROOT, "include")
 LIB_DIR = os.path.join(_PKG, "lib")
 OBJ_DIR = os.path.join(LIB_DIR, "obj")
@@ -48,7 +49,7 @@ def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
     jobs += [(TILES_SRC, os.path.join(OBJ_DIR, f"synth_tiles_r{r}.o"), [f"-DSYNTH_TILE_R={r}"])
              for r in TILE_RADII]
     jobs += [(TILES_SRC, os.path.join(OBJ_DIR, f"synth_tiles_r{r}_bf16.o"),
-              [f"-DSYNTH_TILE_R={r}", "-DSYNTH_TILE_BF16=1"]) for r in TILE_RADII]
+              [f"-DSYNTH_TILE_R={r}", "-DSYNTH_TILE_BF16=1"]) for r in BF16_RADII]
     workers = max(1, min(len(jobs), int(os.environ.get("MAX_JOBS", os.cpu_count() or 1))))
 
     def compile_one(job):

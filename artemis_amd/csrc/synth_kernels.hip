@@ -159,8 +159,14 @@ int tiled_radius(const Geom &g, int tile_radius, int frame_dtype)
     if (!tiled_ok(g)) return 0;
     int R = pick_radius(tile_radius);
     if (R == 0 && frame_dtype == ARTEMIS_SYNTH_FRAME_BF16) R = pick_radius(ARTEMIS_SYNTH_RADIUS_DEFAULT);
+    if (R < 8 && frame_dtype == ARTEMIS_SYNTH_FRAME_BF16) R = 8;  // (smallest radius built for bf16)
     return R;
 }
+
+// bf16 frames are built for radii 8, 14 and 24 only (two objects fewer to compile; a small radius
+// buys a bf16 caller nothing): their smaller requests run the radius-8 kernels.
+template <class FT>
+constexpr bool kSmallRadiiBuilt = std::is_same<FT, float>::value;
 
 template <class FT>
 void dispatch_fwd_tiled(int R, const void *input, const float *weight, const float *offset_y,
@@ -168,8 +174,18 @@ void dispatch_fwd_tiled(int R, const void *input, const float *weight, const flo
 {
     const FT *in = (const FT *)input;
     switch (R) {
-    case 2: launch_fwd_tiled<2, FT>(in, weight, offset_y, offset_x, output, g, st); break;
-    case 4: launch_fwd_tiled<4, FT>(in, weight, offset_y, offset_x, output, g, st); break;
+    case 2:
+        if constexpr (kSmallRadiiBuilt<FT>) {
+            launch_fwd_tiled<2, FT>(in, weight, offset_y, offset_x, output, g, st);
+            break;
+        }
+        [[fallthrough]];
+    case 4:
+        if constexpr (kSmallRadiiBuilt<FT>) {
+            launch_fwd_tiled<4, FT>(in, weight, offset_y, offset_x, output, g, st);
+            break;
+        }
+        [[fallthrough]];
     case 8: launch_fwd_tiled<8, FT>(in, weight, offset_y, offset_x, output, g, st); break;
     case 24: launch_fwd_tiled<24, FT>(in, weight, offset_y, offset_x, output, g, st); break;
     default: launch_fwd_tiled<14, FT>(in, weight, offset_y, offset_x, output, g, st); break;
@@ -183,8 +199,18 @@ void dispatch_bwd_tiled(int R, const void *input, const float *weight, const flo
 {
     const FT *in = (const FT *)input;
     switch (R) {
-    case 2: launch_bwd_tiled<2, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, st); break;
-    case 4: launch_bwd_tiled<4, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, st); break;
+    case 2:
+        if constexpr (kSmallRadiiBuilt<FT>) {
+            launch_bwd_tiled<2, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, st);
+            break;
+        }
+        [[fallthrough]];
+    case 4:
+        if constexpr (kSmallRadiiBuilt<FT>) {
+            launch_bwd_tiled<4, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, st);
+            break;
+        }
+        [[fallthrough]];
     case 8: launch_bwd_tiled<8, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, st); break;
     case 24: launch_bwd_tiled<24, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, st); break;
     default: launch_bwd_tiled<14, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, st); break;
@@ -196,8 +222,18 @@ void dispatch_head_fwd(int R, const float *w, const float *oy, const float *ox, 
                               const Geom &g, const HeadArgs &ha, hipStream_t st)
 {
     switch (R) {
-    case 2: launch_head_fwd<2, FT>(w, oy, ox, out, g, ha, st); break;
-    case 4: launch_head_fwd<4, FT>(w, oy, ox, out, g, ha, st); break;
+    case 2:
+        if constexpr (kSmallRadiiBuilt<FT>) {
+            launch_head_fwd<2, FT>(w, oy, ox, out, g, ha, st);
+            break;
+        }
+        [[fallthrough]];
+    case 4:
+        if constexpr (kSmallRadiiBuilt<FT>) {
+            launch_head_fwd<4, FT>(w, oy, ox, out, g, ha, st);
+            break;
+        }
+        [[fallthrough]];
     case 8: launch_head_fwd<8, FT>(w, oy, ox, out, g, ha, st); break;
     case 24: launch_head_fwd<24, FT>(w, oy, ox, out, g, ha, st); break;
     default: launch_head_fwd<14, FT>(w, oy, ox, out, g, ha, st); break;
@@ -210,8 +246,18 @@ void dispatch_head_bwd(int R, const float *w, const float *oy, const float *ox,
                               const HeadArgs &ha, hipStream_t st)
 {
     switch (R) {
-    case 2: launch_head_bwd<2, FT>(w, oy, ox, gout, gw, goy, gox, g, ha, st); break;
-    case 4: launch_head_bwd<4, FT>(w, oy, ox, gout, gw, goy, gox, g, ha, st); break;
+    case 2:
+        if constexpr (kSmallRadiiBuilt<FT>) {
+            launch_head_bwd<2, FT>(w, oy, ox, gout, gw, goy, gox, g, ha, st);
+            break;
+        }
+        [[fallthrough]];
+    case 4:
+        if constexpr (kSmallRadiiBuilt<FT>) {
+            launch_head_bwd<4, FT>(w, oy, ox, gout, gw, goy, gox, g, ha, st);
+            break;
+        }
+        [[fallthrough]];
     case 8: launch_head_bwd<8, FT>(w, oy, ox, gout, gw, goy, gox, g, ha, st); break;
     case 24: launch_head_bwd<24, FT>(w, oy, ox, gout, gw, goy, gox, g, ha, st); break;
     default: launch_head_bwd<14, FT>(w, oy, ox, gout, gw, goy, gox, g, ha, st); break;
@@ -525,6 +571,7 @@ static int head_setup(Geom &g, HeadArgs &ha, const char *what, const void *const
     if (const int e = check_frame_dtype(g, frame_dtype, what)) return e;
     R = pick_radius(tile_radius);
     if (R == 0) R = pick_radius(ARTEMIS_SYNTH_RADIUS_DEFAULT);  // the head has no direct variant
+    if (R < 8 && frame_dtype == ARTEMIS_SYNTH_FRAME_BF16) R = 8;  // (smallest radius built for bf16)
     return 0;
 }
 

@@ -67,7 +67,8 @@ extern "C" {
 /* frame_dtype of the *_ex and head entry points: element type of the frame(s).  The reference is
  * fp32 only (cupy_module/synth.py:9-13 declares float everywhere); bf16 frames (BASELINE configs[4])
  * are widened exactly to fp32 when staged, all arithmetic and every other tensor stay fp32.  bf16 is
- * built for k = 5, d = 1, C = 3 (with RADIUS_NONE meaning the default radius). */
+ * built for k = 5, d = 1, C = 3 and tile radii 8, 14 and 24 (RADIUS_NONE means the default radius, a
+ * smaller request runs the radius-8 kernels). */
 #define ARTEMIS_SYNTH_FRAME_F32 0
 #define ARTEMIS_SYNTH_FRAME_BF16 1
 
