@@ -140,7 +140,7 @@ def test_random_motion_fields_against_oracle(dev, oracle, case):
     N = int(rng.integers(1, 3))
     H = int(rng.choice([16, 33, 48, 70, 100]))
     W = int(rng.choice([64, 100, 128, 150, 257, 300]))
-    radius = int(rng.choice([-1, -1, 2, 4, 8]))
+    radius = int(rng.choice([-1, -1, 2, 4, 8, 24]))
     big_tiles = bool(rng.integers(2))
     old = lib.artemis_synth_set_small_grid_tiles(0 if big_tiles else 1 << 40)
     tag = f"case {case} N{N} {H}x{W} R{radius} big{big_tiles}"
