@@ -363,6 +363,8 @@ def run_train(args, rank, world, device, dist, backend):
     bwd_gbs = BWD_BYTES * B * H * W / (bwd_ms * 1e-3) / 1e9
     fwd_gbs = FWD_BYTES * B * H * W / (fwd_ms * 1e-3) / 1e9
     traffic, traffic_src = recorded_traffic("synth_bwd_bytes_per_launch", B)
+    if args.radius != -1 or args.sigma != 1.0:  # (recorded at the default radius, sigma 1)
+        traffic, traffic_src = None, "profiles/pmc_traffic.json holds the default radius at sigma 1 only"
     line = {
         "metric": "synthesized Mpix/s fwd+bwd (4 frames, 1080p)",
         "value": round(value, 2),
@@ -476,6 +478,12 @@ def run_interp7(args, rank, world, device, dist, backend):
         return None
     kernel_ms = e0.elapsed_time(e1) / args.steps
     value = TS * H * W / (ms * 1e-3) / 1e6
+    # recorded for one 1080p sample (tools/prof_run.py --head); this launch holds n samples of Hl rows
+    traffic, traffic_src = recorded_traffic("head_fwd_bytes_per_launch", 1)
+    if traffic is not None and args.radius == -1:
+        traffic = int(traffic * n * Hl / H)
+    else:
+        traffic = None
     gbs = HEAD_FWD_BYTES * n * Hl * W / (kernel_ms * 1e-3) / 1e9
     busy = world if sh.y1 - sh.y0 < H else min(world, TS)
     return {
@@ -497,7 +505,7 @@ def run_interp7(args, rank, world, device, dist, backend):
         "roofline": {
             "kernel": "synth_fwd_tapmajor<HEAD> (fused 4-frame head forward), rank 0's launch",
             "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": round(HEAD_FWD_BYTES * n * Hl * W),
             "avg_launch_ms": round(kernel_ms, 4),
         },
