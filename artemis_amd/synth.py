@@ -376,3 +376,16 @@ def offset_radius(offset_y, offset_x) -> torch.Tensor:
             _ptr(offset_y), _ptr(offset_x), offset_y.numel(), _ptr(out),
             torch.cuda.current_stream().cuda_stream), "artemis_synth_offset_radius")
     return out
+
+
+def suggest_tile_radius(offset_y, offset_x) -> int:
+    """A ``tile_radius`` for offsets like these -- ONE host synchronisation (``.item()``), so call it
+    on a representative batch once, not per step, and set ``options.tile_radius`` from it.  Offsets
+    whose whole-pixel part stays within the default window (14) are served by the default shape,
+    which is the fastest there; anything larger gets 24, the one-window-per-64x32-tile shape that
+    costs 4-6 % on small offsets and wins 8-60 % on large steep or scattered ones.
+    (A large but uniform displacement -- a pan -- would run as fast at the default: the scalar
+    cannot tell it from a steep flow.)"""
+    reach = int(offset_radius(offset_y, offset_x).item())
+    return _lib.RADIUS_DEFAULT if reach <= 14 else 24
+

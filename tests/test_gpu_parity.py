@@ -208,6 +208,20 @@ def test_offset_radius_helper(dev):
     assert int(artemis_amd.offset_radius(oy, ox)) == 2**31 - 1
 
 
+def test_suggest_tile_radius(dev):
+    import artemis_amd
+    from artemis_amd import _lib
+    oy = torch.randn(1, 25, 16, 64, device=dev)
+    ox = torch.randn(1, 25, 16, 64, device=dev)
+    assert artemis_amd.suggest_tile_radius(oy, ox) == _lib.RADIUS_DEFAULT   # within the default window
+    oy[0, 7, 3, 3] = 14.9
+    assert artemis_amd.suggest_tile_radius(oy, ox) == _lib.RADIUS_DEFAULT
+    oy[0, 7, 3, 3] = -15.0
+    assert artemis_amd.suggest_tile_radius(oy, ox) == 24
+    with artemis_amd.synth_options(tile_radius=artemis_amd.suggest_tile_radius(oy, ox)):
+        assert artemis_amd.options.tile_radius == 24
+
+
 def test_runs_on_the_callers_stream(dev, oracle):
     import artemis_amd
     inp, w, oy, ox, gout = make_operands(1, 3, 32, 64, regime="gauss1", seed=15)
