@@ -135,6 +135,12 @@ def main(argv=None):
     args = get_args(argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    # main.py:23-24 (`if args.cuda: torch.backends.cudnn.benchmark = True`): on ROCm this is MIOpen's
+    # find mode -- the convolutions of encoder / decoder / sub-networks are benchmarked once per shape
+    torch.backends.cudnn.benchmark = True
+    if world > 1 and args.mode == "train":
+        from .train import rehearsal_env
+        rehearsal_env(args.backend)
     if world > 1 and args.backend != "nccl" and args.device == "auto":
         args.device = str(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
     device = select_device(args.device)

@@ -7,8 +7,9 @@ the reference's ``main.py`` that touch the hot path
 
 The op itself needs no collective: the batch is sharded over ranks (``sharding.shard_batch``) and
 the only exchange of a step is DDP's gradient all-reduce of the module's parameters (29.09 M fp32 for
-the full model, RCCL over xGMI with backend ``nccl``; ``gloo`` works for rehearsals).  With
-``--model head`` the encoder/decoder are stood in for by given feature tensors.
+the full model, RCCL over xGMI with backend ``nccl``; ``gloo`` works for rehearsals on fewer GPUs
+than ranks -- see ``rehearsal_env``).  With ``--model head`` the encoder/decoder are stood in for by
+given feature tensors.
 
     torchrun --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m artemis_amd.train \
         --model artemis --batch 64 --size 256 --steps 5        # BASELINE configs[2]
@@ -24,6 +25,20 @@ import torch.nn as nn
 from .device import add_device_argument, select_device
 from .model import ArTEMIS, ChronoSynth
 from .sharding import shard_bounds
+
+
+def rehearsal_env(backend):
+    """DistributedDataParallel over ``gloo`` with CUDA tensors needs the HIP runtime's queue-thread
+    mode on ROCm 7.0 / this PyTorch build: ProcessGroupGloo stages each bucket through a pinned host
+    copy on a side stream that waits on an event of the compute stream and is then synchronised
+    from gloo's worker thread; in direct-dispatch mode that ``hipStreamSynchronize`` never returns
+    once the event is still pending when the wait is issued (any model whose backward keeps the
+    queue busy; one process is enough; none of this package's kernels need be involved --
+    DESIGN.md 6, tools/ddp_probe.py, tools/dbg/hip_wait_repro.py).  ``AMD_DIRECT_DISPATCH=0`` must
+    be in the environment before the first HIP call of the process.  Backend ``nccl`` (RCCL, the
+    production path) is not affected and is left alone."""
+    if backend != "nccl":
+        os.environ.setdefault("AMD_DIRECT_DISPATCH", "0")
 
 
 def synthetic_batch(batch, num_features, size, seed, device):
@@ -63,12 +78,10 @@ class HeadTrainer:
         self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
         self.rank = torch.distributed.get_rank() if self.world > 1 else 0
         self.model = self.module
-        # RCCL (backend "nccl"): DistributedDataParallel, bucketed all-reduce overlapped with the
-        # backward.  Any other backend is a rehearsal of the multi-rank control flow on fewer GPUs
-        # than ranks (gloo, ranks sharing a device): gradients are averaged by one all-reduce of
-        # the flattened gradient on the host instead -- DDP's bucketed CUDA all-reduce over gloo
-        # stalls for the full model when two ranks share one GPU.
-        self.ddp = self.world > 1 and torch.distributed.get_backend() == "nccl"
+        # DistributedDataParallel whenever a process group is up (also a group of one rank, so that
+        # a one-GPU box can run the RCCL path): bucketed gradient all-reduce overlapped with the
+        # backward -- RCCL with backend "nccl", gloo for rehearsals (see rehearsal_env).
+        self.ddp = torch.distributed.is_initialized()
         if self.ddp:
             self.model = nn.parallel.DistributedDataParallel(
                 self.module, device_ids=[device.index], broadcast_buffers=False)
@@ -97,22 +110,8 @@ class HeadTrainer:
         out = self.model(feats, frames, tuple(gt.shape[-2:]), t)
         loss = self.loss(out, gt)
         loss.backward()                  # DDP all-reduces (averages) the parameter gradients here
-        self.average_gradients()
         self.optimizer.step()
         return loss.detach()
-
-    def average_gradients(self):
-        """The rehearsal path's gradient all-reduce (see __init__); a no-op under DDP."""
-        if self.world == 1 or self.ddp:
-            return
-        params = [p for p in self.module.parameters() if p.grad is not None]
-        flat = torch.cat([p.grad.reshape(-1) for p in params]).cpu()
-        torch.distributed.all_reduce(flat)
-        flat = (flat / self.world).to(self.device)
-        o = 0
-        for p in params:
-            p.grad.copy_(flat[o:o + p.numel()].view_as(p.grad))
-            o += p.numel()
 
     def end_epoch(self):
         """Step the LR schedule: once per epoch, as Lightning does for main.py:89-95."""
@@ -141,8 +140,7 @@ class ModelTrainer(HeadTrainer):
         self.optimizer.zero_grad(set_to_none=True)
         _, _, out = self.model(frames, t)
         loss = self.loss(out, gt)
-        loss.backward()
-        self.average_gradients()
+        loss.backward()                  # DDP: the 29.09 M gradients' all-reduce, bucketed
         self.optimizer.step()
         return loss.detach()
 
@@ -159,17 +157,26 @@ def main(argv=None):
     ap.add_argument("--backend", default=os.environ.get("ARTEMIS_DIST_BACKEND", "nccl"))
     ap.add_argument("--composed", action="store_true", help="reference composition instead of the fused head")
     ap.add_argument("--dump", default="", help="rank 0 writes the final parameters here (tests)")
+    ap.add_argument("--cudnn_benchmark", type=int, default=1,
+                    help="main.py:23-24 sets torch.backends.cudnn.benchmark (MIOpen find mode on ROCm); "
+                         "0 = immediate mode (short test runs: finding costs seconds per conv shape)")
     args = ap.parse_args(argv)
     if os.environ.get("ARTEMIS_TRACE_HANG"):      # debugging aid: where is every thread after N s?
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["ARTEMIS_TRACE_HANG"]), exit=True)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # ARTEMIS_FORCE_DIST=1: bring the process group up for a single rank too (under
+    # torch.distributed.run), so that DistributedDataParallel + RCCL run on a one-GPU box
+    dist_on = world > 1 or os.environ.get("ARTEMIS_FORCE_DIST") == "1"
+    torch.backends.cudnn.benchmark = bool(args.cudnn_benchmark)
+    if dist_on:
+        rehearsal_env(args.backend)
     if world > 1 and args.backend != "nccl" and args.device == "auto":
         # rehearsal on fewer GPUs than ranks: wrap around the visible devices
         args.device = str(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
     device = select_device(args.device)
-    if world > 1:
+    if dist_on:
         kw = {"device_id": device} if args.backend == "nccl" else {}
         torch.distributed.init_process_group(args.backend, **kw)
     full = args.model == "artemis"
@@ -183,7 +190,7 @@ def main(argv=None):
         loss = tr.step(batch)
         if (i + 1) % args.steps == 0:
             tr.end_epoch()
-        if world > 1:
+        if dist_on:
             torch.distributed.all_reduce(loss, op=torch.distributed.ReduceOp.AVG
                                          if args.backend == "nccl" else torch.distributed.ReduceOp.SUM)
             if args.backend != "nccl":
@@ -192,7 +199,7 @@ def main(argv=None):
             print(f"step {i}: loss {float(loss):.6f} lr {tr.scheduler.get_last_lr()[0]:.2e}", flush=True)
     if args.dump and tr.rank == 0:
         torch.save({k: v.detach().cpu() for k, v in tr.module.state_dict().items()}, args.dump)
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

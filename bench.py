@@ -71,22 +71,26 @@ def make_offsets(regime, shape, device, g):
     raise KeyError(regime)
 
 
-def make_frames(batch, sigma, device, seed, regime=None):
+def make_frames(batch, sigma, device, seed, regime=None, size=None, backward=True):
     """Synthetic operands per SURVEY.md 8d: frames rand in [0,1] replication-padded by 2, weights
-    softmax over 25 N(0,1) logits, offsets per `regime` (default N(0, sigma^2)), gradOutput randn."""
+    softmax over 25 N(0,1) logits, offsets per `regime` (default N(0, sigma^2)), gradOutput randn.
+    size: (h, w) of the output, default 1080 x 1920; backward=False leaves out the gradient tensors."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     regime = regime or f"sigma:{sigma}"
+    h, w_ = size or (H, W)
     frames = []
     for _ in range(FRAMES):
-        frame = torch.rand(batch, C, H, W, device=device, generator=g)
+        frame = torch.rand(batch, C, h, w_, device=device, generator=g)
         inp = torch.nn.functional.pad(frame, (PAD,) * 4, mode="replicate").contiguous()
-        w = torch.softmax(torch.randn(batch, K_TAPS, H, W, device=device, generator=g), 1)
-        oy, ox = make_offsets(regime, (batch, K_TAPS, H, W), device, g)
-        gout = torch.randn(batch, C, H, W, device=device, generator=g)
-        out = torch.empty(batch, C, H, W, device=device)
-        gw, ga, gb = (torch.empty(batch, K_TAPS, H, W, device=device) for _ in range(3))
-        frames.append(dict(inp=inp, w=w, oy=oy, ox=ox, gout=gout, out=out, gw=gw, ga=ga, gb=gb))
+        w = torch.softmax(torch.randn(batch, K_TAPS, h, w_, device=device, generator=g), 1)
+        oy, ox = make_offsets(regime, (batch, K_TAPS, h, w_), device, g)
+        out = torch.empty(batch, C, h, w_, device=device)
+        f = dict(inp=inp, w=w, oy=oy, ox=ox, out=out)
+        if backward:
+            f["gout"] = torch.randn(batch, C, h, w_, device=device, generator=g)
+            f["gw"], f["ga"], f["gb"] = (torch.empty(batch, K_TAPS, h, w_, device=device) for _ in range(3))
+        frames.append(f)
     return frames
 
 
@@ -146,12 +150,30 @@ def cpu_baseline(threads, sigma):
         "value": round(H * W / 1e6 / (dt * FRAMES), 3), "unit": "Mpix/s", "cores": threads,
         "sample": f"1 frame of 1080x1920 fwd + autograd bwd (oracle.forward_torch), {dt:.1f} s, x{FRAMES} "
                   "frames per step"}
+    res["config2_forward"] = _config2_cpu(so, rng, sigma)
+    return res
+
+
+def cpu_baseline_config2(threads, sigma):
+    """cpu_baseline object of `--workload config2`: the oracle's C port (and the PyTorch
+    transcription) on configs[1]'s own shape."""
+    import numpy as np
+    from oracle import synth_oracle as so
+    so.set_threads(threads)
+    torch.set_num_threads(threads)
+    c = _config2_cpu(so, np.random.default_rng(103), sigma, budget_s=12.0)
+    return {"value": c["port"], "unit": "Mpix/s", "cores": threads, "host_cpus": os.cpu_count(),
+            "kind": "port", "sample": c["sample"],
+            "torch_transcription": {"value": c["torch_transcription"], "unit": "Mpix/s", "cores": threads}}
+
+
+def _config2_cpu(so, rng, sigma, budget_s=3.0):
     # configs[1]: N = 16, 256 x 448, 4 frames, forward only
     n2, h2, w2 = 16, 256, 448
     inp, wt, oy, ox, _ = _cpu_operands(rng, n2, h2, w2, sigma)
     t0 = time.perf_counter()
     reps = 0
-    while reps < 1 or (time.perf_counter() - t0 < 3.0 and reps < 8):
+    while reps < 1 or (time.perf_counter() - t0 < budget_s and reps < 32):
         so.forward(inp, wt, oy, ox, 1)
         reps += 1
     dt = (time.perf_counter() - t0) / reps
@@ -160,7 +182,7 @@ def cpu_baseline(threads, sigma):
     with torch.no_grad():
         so.forward_torch(*tt, 1)
     dtt = (time.perf_counter() - t0) * (n2 / 2)
-    res["config2_forward"] = {
+    return {
         "workload": "N=16, 256x448, 4 frames, forward only (BASELINE.json configs[1])",
         "unit": "Mpix/s (synthesized: 4 frame calls per pixel)",
         "port": round(n2 * h2 * w2 / 1e6 / (dt * FRAMES), 3),
@@ -168,7 +190,6 @@ def cpu_baseline(threads, sigma):
         "sample": f"port: {reps} x one frame call of all 16 samples ({dt:.2f} s each); transcription: "
                   f"2 of 16 samples once, scaled; both x{FRAMES} frames",
     }
-    return res
 
 
 def head_operands(B, device, regime, seed):
@@ -270,19 +291,20 @@ def recorded_traffic(key, batch):
 class Op:
     """fwd / bwd launchers of one operand set list through the C ABI."""
 
-    def __init__(self, lib, frames, B, radius, stream):
+    def __init__(self, lib, frames, B, radius, stream, size=None):
         self.lib, self.frames, self.B, self.radius, self.stream = lib, frames, B, radius, stream
+        self.h, self.w = size or (H, W)
 
     def fwd(self, f):
         _lib.check(self.lib.artemis_synth_forward(
             f["inp"].data_ptr(), f["w"].data_ptr(), f["oy"].data_ptr(), f["ox"].data_ptr(),
-            f["out"].data_ptr(), self.B, C, H, W, 5, 1, self.radius, self.stream), "forward")
+            f["out"].data_ptr(), self.B, C, self.h, self.w, 5, 1, self.radius, self.stream), "forward")
 
     def bwd(self, f):
         _lib.check(self.lib.artemis_synth_backward(
             f["inp"].data_ptr(), f["w"].data_ptr(), f["oy"].data_ptr(), f["ox"].data_ptr(),
             f["gout"].data_ptr(), None, f["gw"].data_ptr(), f["ga"].data_ptr(),
-            f["gb"].data_ptr(), self.B, C, H, W, 5, 1, _lib.GIN_ATOMIC, self.radius, None, 0,
+            f["gb"].data_ptr(), self.B, C, self.h, self.w, 5, 1, _lib.GIN_ATOMIC, self.radius, None, 0,
             self.stream), "backward")
 
     def step(self, events=None):
@@ -413,9 +435,122 @@ def run_train(args, rank, world, device, dist, backend):
                 for r in args.regimes.split(",")}
         if not args.no_head:
             line["config"]["chrono_head_fwd_bwd_1080p"] = head_timing(device, args.radius, args.sigma)
+            line["config"]["config2_forward_gpu"] = config2_gpu_quick(lib, device, args.radius, stream,
+                                                                      args.sigma)
         if not args.no_cpu_baseline:  # reported at N = 1 only
             threads = args.cpu_threads or min(16, os.cpu_count() or 1)
             line["cpu_baseline"] = cpu_baseline(threads, args.sigma)
+    return line
+
+
+CONFIG2_SHAPE = (16, 256, 448)   # N, H, W of BASELINE.json configs[1]
+
+
+def config2_fwd_bytes():
+    """Algorithmic bytes of ONE forward launch at configs[1]'s shape (324 B/pixel)."""
+    n2, h2, w2 = CONFIG2_SHAPE
+    return (3 * K_TAPS * 4 + C * 4) * n2 * h2 * w2 + C * 4 * n2 * (h2 + 2 * PAD) * (w2 + 2 * PAD)
+
+
+def config2_gpu_quick(lib, device, radius, stream, sigma, steps=10):
+    """configs[1] on the GPU beside the headline (the full line: --workload config2): 4 forward
+    launches of N = 16 x 256 x 448 per step, HIP events."""
+    n2, h2, w2 = CONFIG2_SHAPE
+    frames = make_frames(n2, sigma, device, seed=503, size=(h2, w2), backward=False)
+    op = Op(lib, frames, n2, radius, stream, size=(h2, w2))
+    for _ in range(3):
+        for f in frames:
+            op.fwd(f)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        for f in frames:
+            op.fwd(f)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    gbs = config2_fwd_bytes() * FRAMES / (ms * 1e-3) / 1e9
+    del frames, op
+    torch.cuda.empty_cache()
+    return {"workload": "N=16, 256x448, 4 frames, forward only (BASELINE.json configs[1]), 1 GPU",
+            "Mpix_s": round(n2 * h2 * w2 / (ms * 1e-3) / 1e6, 1), "ms_per_step": round(ms, 4),
+            "fwd_kernel_ms": round(ms / FRAMES, 4), "GBps": round(gbs, 1),
+            "hbm_frac_of_8TBps": round(gbs / HBM_PEAK_GBS, 4)}
+
+
+def run_config2(args, rank, world, device, dist, backend):
+    """BASELINE.json configs[1]: "Synth op forward only, Vimeo-90K septuplet shape 448x256, batch 16,
+    4 frames, config.py default taps, fp32, 1xMI355X" (operand shapes of model/chrono_synth.py:109-127
+    at the dataset's native size, data/preprocessing/vimeo90k_septuplet_process.py:36).  A step = the
+    4 per-frame forward launches of one head at N = 16 (2.38 GB of operands per step, so every launch
+    streams cold planes: the 4 frames' sets rotate through 9x the Infinity Cache); `value` =
+    synthesized pixels (N x 256 x 448 per step) / time.  On N ranks every rank runs its own batch of
+    16 (weak scaling, no collective)."""
+    lib = _lib.load()
+    n2, h2, w2 = CONFIG2_SHAPE
+    frames = make_frames(n2, args.sigma, device, seed=503 + rank, size=(h2, w2), backward=False)
+    stream = torch.cuda.current_stream().cuda_stream
+    op = Op(lib, frames, n2, args.radius, stream, size=(h2, w2))
+
+    def step():
+        for f in frames:
+            op.fwd(f)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    ms = (t1 - t0) * 1e3 / args.steps
+    if dist is not None:
+        tt = torch.tensor([ms], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ms = float(tt.item())
+    if rank != 0:
+        return None
+    kernel_ms = e0.elapsed_time(e1) / (args.steps * FRAMES)
+    fwd_bytes = config2_fwd_bytes()
+    gbs = fwd_bytes / (kernel_ms * 1e-3) / 1e9
+    value = world * n2 * h2 * w2 / (ms * 1e-3) / 1e6
+    line = {
+        "metric": "synthesized Mpix/s fwd (4 frames, 448x256, batch 16)",
+        "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": "config2: synth op forward only, N=16 x 256x448 (Vimeo-90K septuplet), 4 frames "
+                        "= 4 launches per step (BASELINE.json configs[1]), k=5 d=1 C=3, fp32",
+            "batch_per_gpu": n2, "offset_regime": f"sigma:{args.sigma:g}", "tile_radius": args.radius,
+            "tile_radius_note": "-1 = the library default (what FunctionSynth callers get)",
+            "operand_bytes_per_step": FRAMES * fwd_bytes,
+            "sharding": "batch, no collective",
+        },
+        "roofline": {
+            "kernel": "synth_fwd_tapmajor (one frame's forward at N = 16)",
+            "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            "traffic_source": "not recorded for this shape (per-pixel traffic: profiles/pmc_traffic.json, 1080p)",
+            "algorithmic_bytes_per_launch": fwd_bytes, "avg_launch_ms": round(kernel_ms, 4),
+        },
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        del frames, op
+        torch.cuda.empty_cache()
+        threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+        line["cpu_baseline"] = cpu_baseline_config2(threads, args.sigma)
     return line
 
 
@@ -517,8 +652,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=["train", "interp7"], default="train",
-                    help="train = the headline (op fwd+bwd, 4 frames, 1080p); interp7 = configs[3]")
+    ap.add_argument("--workload", choices=["train", "config2", "interp7"], default="train",
+                    help="train = the headline (op fwd+bwd, 4 frames, 1080p); config2 = configs[1] (op "
+                         "forward, N=16 x 256x448, 4 frames); interp7 = configs[3]")
     ap.add_argument("--interp-shard", choices=["auto", "timesteps"], default="auto",
                     help="interp7 on N ranks: auto = sharding.shard_interpolation (row strips of all "
                          "timesteps when N does not divide 7); timesteps = whole timesteps only")
@@ -556,7 +692,7 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    run = run_train if args.workload == "train" else run_interp7
+    run = {"train": run_train, "config2": run_config2, "interp7": run_interp7}[args.workload]
     line = run(args, rank, world, device, dist, backend)
     if rank == 0:
         print(json.dumps(line))

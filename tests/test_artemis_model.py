@@ -312,26 +312,29 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_train(world, dump):
-    env = dict(os.environ, PYTHONPATH=ROOT, ARTEMIS_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    args = ["--model", "artemis", "--steps", "2", "--batch", "2", "--size", "64", "--dump", dump]
-    if world == 1:
+def _run_train(world, dump, backend="gloo", force_dist=False):
+    """`python -m artemis_amd.train --model artemis`: world 1 without a process group, or under
+    torch.distributed.run with DistributedDataParallel over `backend` (force_dist: a group of ONE
+    rank, so that DDP + RCCL run on the box's one GPU).  ARTEMIS_TRACE_HANG: should a rank stall,
+    its stacks are in the assertion message instead of a silent timeout."""
+    env = dict(os.environ, PYTHONPATH=ROOT, ARTEMIS_DIST_BACKEND=backend, MASTER_ADDR="127.0.0.1",
+               ARTEMIS_TRACE_HANG="150")
+    env.pop("AMD_DIRECT_DISPATCH", None)      # train.rehearsal_env must set it by itself for gloo
+    if force_dist:
+        env["ARTEMIS_FORCE_DIST"] = "1"
+    args = ["--model", "artemis", "--steps", "2", "--batch", "2", "--size", "64", "--dump", dump, "--cudnn_benchmark", "0"]
+    if world == 1 and not force_dist:
         cmd = [sys.executable, "-m", "artemis_amd.train", "--device", "hip:0"] + args
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "-m",
-               "artemis_amd.train", "--backend", "gloo"] + args
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+               "artemis_amd.train", "--backend", backend] + args
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=400)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     return [float(ln.split()[3]) for ln in r.stdout.splitlines() if ln.startswith("step ")]
 
 
-@pytest.mark.gpu
-def test_full_model_two_ranks_follow_the_single_process_run(tmp_path):
-    """The full-model train step (Adamax, MultiStepLR, L1, DDP) with the batch sharded over two
-    ranks (gloo, sharing the box's one GPU) follows the single-process run on the whole batch."""
-    one, two = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")
-    loss1, loss2 = _run_train(1, one), _run_train(2, two)
+def _same_training_run(one, two, loss1, loss2):
     assert len(loss1) == 2 and len(loss2) == 2
     for a, b in zip(loss1, loss2):
         assert abs(a - b) <= 1e-4 * max(abs(a), 1.0), (loss1, loss2)
@@ -350,3 +353,26 @@ def test_full_model_two_ranks_follow_the_single_process_run(tmp_path):
             bad += int((diff > 1e-4 * max(scale, 1e-3)).sum())
             total += diff.numel()
     assert bad <= 1e-4 * total, (bad, total)
+
+
+@pytest.mark.gpu
+def test_full_model_ddp_over_rccl_single_rank(tmp_path):
+    """The production branch of the train step -- DistributedDataParallel over backend `nccl` (RCCL)
+    around the whole model, fused head op included (main.py:133's Lightning DDP) -- executed on the
+    box's one GPU as a process group of one rank (ARTEMIS_FORCE_DIST=1): init, parameter broadcast,
+    bucketed gradient all-reduce during the backward, Adamax step; same losses and parameters as
+    the plain single-process run."""
+    one, two = str(tmp_path / "plain.pt"), str(tmp_path / "rccl.pt")
+    loss1 = _run_train(1, one)
+    loss2 = _run_train(1, two, backend="nccl", force_dist=True)
+    _same_training_run(one, two, loss1, loss2)
+
+
+@pytest.mark.gpu
+def test_full_model_two_ranks_follow_the_single_process_run(tmp_path):
+    """The full-model train step (Adamax, MultiStepLR, L1) under DistributedDataParallel with the
+    batch sharded over two ranks (gloo, sharing the box's one GPU: train.rehearsal_env) follows the
+    single-process run on the whole batch."""
+    one, two = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")
+    loss1, loss2 = _run_train(1, one), _run_train(2, two)
+    _same_training_run(one, two, loss1, loss2)

@@ -1,4 +1,12 @@
-"""BASELINE.json configs[2], [3], [4] at their STATED sizes on the GPU against the CPU oracle.
+"""BASELINE.json configs[1], [2], [3], [4] at their STATED sizes on the GPU against the CPU oracle.
+
+* configs[1] "Synth op forward only, Vimeo-90K septuplet shape 448x256, batch 16, 4 frames": one
+  forward launch of N = 16 x 256 x 448 (operand shapes of model/chrono_synth.py:109-127 at the
+  dataset's native size, data/preprocessing/vimeo90k_septuplet_process.py:36) at the default
+  radius -- 896 big tiles, i.e. the 128 x 16 kernels with N in the tile index -- per context frame;
+  samples 0 and 15 in full against the oracle, every sample against its own N = 1 launch with the
+  small-grid knob forced to 0 (the same kernels on a grid of 56 tiles), bit for bit; the same for
+  the fused head.
 
 * configs[3] "Interpolate mode at 1080p, one 4-frame window, 7 timesteps batched as one launch":
   the op and the fused head at N = 7 x 1080 x 1920 in one launch (main.py:114-121 runs the
@@ -42,6 +50,78 @@ def fast_oracle(oracle):
 
 def np_(t):
     return np.ascontiguousarray(t.detach().float().cpu().numpy())
+
+
+# ------------------------------------------------------------------ configs[1]: N = 16 x 256 x 448
+
+def _big_tiles_only(lib):
+    """Context: small-grid knob 0 (every launch takes the 128 x 16 tile kernels)."""
+    import contextlib
+
+    @contextlib.contextmanager
+    def cm():
+        old = lib.artemis_synth_set_small_grid_tiles(-1)
+        lib.artemis_synth_set_small_grid_tiles(0)
+        try:
+            yield old
+        finally:
+            lib.artemis_synth_set_small_grid_tiles(old)
+    return cm()
+
+
+@pytest.mark.parametrize("sigma", [1.0, 0.045])
+def test_config1_op_forward_batch16_vimeo_shape(dev, fast_oracle, sigma):
+    import artemis_amd
+    from artemis_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device=dev).manual_seed(16)
+    N, H, W, T = 16, 256, 448, 4
+    knob = lib.artemis_synth_set_small_grid_tiles(-1)
+    # the launch must be on the big-tile side of the forward's switch (a quarter of the knob)
+    assert N * ((H + 31) // 32) * ((W + 63) // 64) >= (knob + 3) // 4      # the library's count: 64 x 32 units
+    for f in range(T):                                   # the 4 context frames = the 4 op calls
+        inp = torch.nn.functional.pad(torch.rand(N, 3, H, W, device=dev, generator=g), (2,) * 4,
+                                      mode="replicate").contiguous()
+        w = torch.softmax(torch.randn(N, 25, H, W, device=dev, generator=g), 1)
+        oy = torch.randn(N, 25, H, W, device=dev, generator=g) * sigma
+        ox = torch.randn(N, 25, H, W, device=dev, generator=g) * sigma
+        out = artemis_amd.synth(inp, w, oy, ox, 1)      # ONE launch, default radius
+        torch.cuda.synchronize()
+        assert out.shape == (N, 3, H, W)
+        with _big_tiles_only(lib):
+            for n in range(N):
+                one = artemis_amd.synth(inp[n:n + 1].contiguous(), w[n:n + 1].contiguous(),
+                                        oy[n:n + 1].contiguous(), ox[n:n + 1].contiguous(), 1)
+                assert torch.equal(out[n:n + 1], one), f"frame {f} sample {n}"
+        for n in (0, 15):
+            ref = fast_oracle.forward(np_(inp[n:n + 1]), np_(w[n:n + 1]), np_(oy[n:n + 1]),
+                                      np_(ox[n:n + 1]), 1)
+            parity_close(out[n:n + 1], ref, FWD_RTOL, f"config1 op output N16 256x448 sigma {sigma}")
+
+
+def test_config1_head_forward_batch16_vimeo_shape(dev, fast_oracle):
+    import artemis_amd
+    from artemis_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device=dev).manual_seed(17)
+    B, T, H, W = 16, 4, 256, 448
+    frames = [torch.rand(B, 3, H, W, device=dev, generator=g) for _ in range(T)]
+    w = torch.softmax(torch.randn(B, T, 25, H, W, device=dev, generator=g), 2)
+    a = torch.randn(B, T, 25, H, W, device=dev, generator=g)
+    b = torch.randn(B, T, 25, H, W, device=dev, generator=g)
+    occ = torch.softmax(torch.randn(B, T, H, W, device=dev, generator=g), 1)
+    out = artemis_amd.chrono_head(frames, w, a, b, occ)  # ONE launch: 16 samples x 4 frames
+    torch.cuda.synchronize()
+    with _big_tiles_only(lib):
+        for n in range(B):
+            one = artemis_amd.chrono_head([f[n:n + 1].contiguous() for f in frames],
+                                          w[n:n + 1].contiguous(), a[n:n + 1].contiguous(),
+                                          b[n:n + 1].contiguous(), occ[n:n + 1].contiguous())
+            assert torch.equal(out[n:n + 1], one), f"sample {n}"
+    for n in (0, 15):
+        ref, _ = fast_oracle.head_forward([np_(f[n:n + 1]) for f in frames], np_(w[n:n + 1]),
+                                          np_(a[n:n + 1]), np_(b[n:n + 1]), np_(occ[n:n + 1]), 1)
+        parity_close(out[n:n + 1], ref, FWD_RTOL, f"config1 head output B16 256x448")
 
 
 # ------------------------------------------------------------------ configs[3]: N = 7 x 1080p

@@ -23,7 +23,7 @@ def free_port():
 
 def run_train(tmp_path, world, dump):
     env = dict(os.environ, PYTHONPATH=ROOT, ARTEMIS_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    args = ["--steps", "3", "--batch", "4", "--size", "48", "--features", "16", "--dump", dump]
+    args = ["--steps", "3", "--batch", "4", "--size", "48", "--features", "16", "--dump", dump, "--cudnn_benchmark", "0"]
     if world == 1:
         cmd = [sys.executable, "-m", "artemis_amd.train", "--device", "hip:0"] + args
     else:
