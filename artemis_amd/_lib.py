@@ -15,6 +15,8 @@ _lib = None
 ABI_VERSION = 1
 RADIUS_DEFAULT = -1
 RADIUS_NONE = 0
+RADIUS_AUTO = -2
+RADIUS_SMALL = -3
 GIN_ATOMIC = 0
 GIN_DETERMINISTIC = 1
 FRAME_F32 = 0
@@ -36,6 +38,8 @@ SIGNATURES = {
     "artemis_synth_head_backward": (_i, [_vp, _i] + [_vp] * 9 + [_i] * 9 + [_vp]),
     "artemis_synth_offset_radius": (_i, [_vp, _vp, ctypes.c_size_t, _vp, _vp]),
     "artemis_synth_set_small_grid_tiles": (ctypes.c_longlong, [ctypes.c_longlong]),
+    "artemis_synth_auto_query": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
+    "artemis_synth_auto_reset": (None, []),
     "artemis_synth_version": (ctypes.c_char_p, []),
     "artemis_synth_last_error": (ctypes.c_char_p, []),
 }

@@ -59,17 +59,17 @@ struct HeadArgs {
 // Launchers of the LDS-staged kernels, one explicit instantiation per radius in synth_tiles.hip.
 template <int R, class FT>
 void launch_fwd_tiled(const FT *in, const float *w, const float *oy, const float *ox, float *out,
-                      const Geom &g, hipStream_t st);
+                      const Geom &g, bool lean, unsigned long long *reach_stats, hipStream_t st);
 template <int R, class FT>
 void launch_bwd_tiled(const FT *in, const float *w, const float *oy, const float *ox,
-                      const float *gout, float *gw, float *goy, float *gox, const Geom &g,
+                      const float *gout, float *gw, float *goy, float *gox, const Geom &g, bool lean,
                       hipStream_t st);
 template <int R, class FT>
 void launch_head_fwd(const float *w, const float *oy, const float *ox, float *out, const Geom &g,
-                     const HeadArgs &ha, hipStream_t st);
+                     const HeadArgs &ha, bool lean, unsigned long long *reach_stats, hipStream_t st);
 template <int R, class FT>
 void launch_head_bwd(const float *w, const float *oy, const float *ox, const float *gout, float *gw,
-                     float *goy, float *gox, const Geom &g, const HeadArgs &ha, hipStream_t st);
+                     float *goy, float *gox, const Geom &g, const HeadArgs &ha, bool lean, hipStream_t st);
 template <int R, bool FIXED>
 void launch_gin_tiled(const float *w, const float *oy, const float *ox, const float *gout, float *gin,
                       unsigned char *ws, const Geom &g, int bits, hipStream_t st);
@@ -94,13 +94,34 @@ inline dim3 pixel_grid(const Geom &g, int rows_per_block)
 #ifndef SYNTH_XCD_REMAP
 #define SYNTH_XCD_REMAP 1
 #endif
-inline dim3 tile_grid(const Geom &g, int rows_per_block, int cols_per_block = 64)
+// SYNTH_PAIR_SEGMENTS (default off: measured and dropped).  A frame whose width is an odd
+// number of 64-column segments (448 = 7 x 64, the Vimeo-90K septuplet) leaves a half-empty workgroup
+// at the right edge of every band of 128-wide tiles; pairing consecutive segments of the row-major
+// (band, segment) list instead removes those (960 workgroups instead of 1024 at N = 16, 256 x 448) --
+// and made that forward 8 % SLOWER (117 vs 109 us; backward +-0): 1024 workgroups are exactly four
+// rounds on 256 CUs, the last of them lighter, while 960 full ones leave a quarter of the chip idle
+// through a fourth round of full-length workgroups.
+#ifndef SYNTH_PAIR_SEGMENTS
+#define SYNTH_PAIR_SEGMENTS 0
+#endif
+// `segments` > 1 (one staged window per 64-column wave column, see segment_origin): a workgroup
+// takes `segments` CONSECUTIVE 64-column segments of the row-major list of (band, segment) pairs, so
+// a frame whose width is an odd number of segments (448 = 7 x 64, the Vimeo-90K septuplet) leaves no
+// half-empty workgroup at the right edge of every band.
+inline dim3 tile_grid(const Geom &g, int rows_per_block, int cols_per_block = 64, int segments = 1)
 {
-    const unsigned tiles_x = (unsigned)((g.W + cols_per_block - 1) / cols_per_block);
     const unsigned tiles_y = (unsigned)((g.H + rows_per_block - 1) / rows_per_block);
 #if SYNTH_XCD_REMAP
-    return dim3(((tiles_x * tiles_y + 7) / 8) * 8, 1, (unsigned)g.N);
+    unsigned tiles;
+    if (segments > 1) {
+        const unsigned segs = (unsigned)((g.W + 63) / 64) * tiles_y;
+        tiles = (segs + segments - 1) / segments;
+    } else {
+        tiles = (unsigned)((g.W + cols_per_block - 1) / cols_per_block) * tiles_y;
+    }
+    return dim3(((tiles + 7) / 8) * 8, 1, (unsigned)g.N);
 #else
+    const unsigned tiles_x = (unsigned)((g.W + cols_per_block - 1) / cols_per_block);
     return dim3(tiles_x, tiles_y, (unsigned)g.N);
 #endif
 }
@@ -148,6 +169,38 @@ __device__ __forceinline__ bool tile_origin(const Geom &g, int &tx0, int &ty0)
 #endif
 }
 
+
+// Origin of wave column `c` (of WX) of this workgroup when every wave column has its own staged
+// window (NWIN == WX): the workgroup owns WX consecutive entries of the row-major list of 64-column
+// segments, so its wave columns may sit in different bands (the last segment of one band and the
+// first of the next, when a band has an odd number of segments).  For an even number of segments
+// per band this is exactly tile_origin's mapping.  false: no workgroup.  A wave column past the end
+// of the list gets wx0 = the frame's width rounded up (>= W: inactive, as a right-edge column was).
+template <int TH, int WX>
+__device__ __forceinline__ bool segment_origin(const Geom &g, int c, int &wx0, int &ty0)
+{
+#if SYNTH_XCD_REMAP
+    const unsigned segs_x = (unsigned)(g.W + 63) / 64, bands = (unsigned)(g.H + TH - 1) / TH;
+    const unsigned segs = segs_x * bands, nb = (segs + WX - 1) / WX, per = (nb + 7) / 8;
+    const unsigned t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (t >= nb) return false;
+    const unsigned l = t * WX + (unsigned)c;
+    if (l >= segs) {
+        wx0 = (int)segs_x * 64;
+        ty0 = (int)(bands - 1) * TH;
+        return true;
+    }
+    const unsigned band = l / segs_x;
+    wx0 = (int)(l - band * segs_x) * 64;
+    ty0 = (int)band * TH;
+    return true;
+#else
+    int tx0;
+    if (!tile_origin<TH, 64 * WX>(g, tx0, ty0)) return false;
+    wx0 = tx0 + c * 64;
+    return true;
+#endif
+}
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
@@ -500,6 +553,7 @@ __global__ __launch_bounds__(256) void det_finalize_kernel(const unsigned char *
 // ------------------------------------------------------------------------------------------
 
 constexpr int kTW = 64;
+constexpr int kReachSlots = 32;  // 64-bit counters per statistics record (spreads the waves' atomics)
 
 // Native 4-float vector and its LDS-qualified form.  Tile reads go through an explicit
 // address_space(3) pointer: with a generic pointer hipcc merges the LDS read and the global
@@ -645,6 +699,9 @@ __device__ __forceinline__ Centre tile_centre(const float *__restrict__ ab,
 // ------------------------------------------------------------------------------------------
 #ifndef SYNTH_MAX_PASSES
 #define SYNTH_MAX_PASSES 3
+#endif
+#ifndef SYNTH_HEAD_SYNC_DEDUPE  // (0: a barrier before every frame's fill, as in round 2 -- for A/B builds)
+#define SYNTH_HEAD_SYNC_DEDUPE 1
 #endif
 #ifndef SYNTH_PASS_MIN_PIXELS
 #define SYNTH_PASS_MIN_PIXELS 24
@@ -1236,10 +1293,14 @@ __device__ __forceinline__ int in_branch(int v)
 static __device__ unsigned long long *g_tile_log;
 #endif
 
-template <int R, int WAVES, int ROWS, int OCC, bool HEAD, class FT, int WX = 1, int NWIN = 1>
+// PASSES: how many windows a tile may stage per frame (kMaxPasses; 1 = the first window only: no vote,
+// no further passes -- the lean shape for offsets known to stay within the radius, synth_tiles.hip)
+template <int R, int WAVES, int ROWS, int OCC, bool HEAD, class FT, int WX = 1, int NWIN = 1,
+          int PASSES = kMaxPasses>
 __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
     const FT *__restrict__ in, const float *__restrict__ w, const float *__restrict__ oy,
-    const float *__restrict__ ox, float *__restrict__ out, Geom g, HeadArgs ha)
+    const float *__restrict__ ox, float *__restrict__ out, Geom g, HeadArgs ha,
+    unsigned long long *__restrict__ reach_stats)
 {
     // WX waves side by side: the tile is 64 * WX pixels wide and (WAVES / WX) * ROWS rows high
     constexpr int TW = 64 * WX, WY = WAVES / WX, TH = WY * ROWS;
@@ -1256,12 +1317,21 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
     unsigned long long dbg_t1 = 0, dbg_t2 = 0, dbg_a = 0, dbg_b = 0, dbg_c = 0;
     int dbg_p = 0, dbg_left = 0;
 #endif
-    int tx0, ty0;
-    if (!tile_origin<TH, TW>(g, tx0, ty0)) return;
     const int n = blockIdx.z;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
-    const int wy = wv / WX, wx0 = tx0 + (wv % WX) * 64;  // the wave's first row slot and column
-    const int wi = (wv % WX) / WXW, sx0 = tx0 + wi * SW;  // its window and that window's first column
+    const int wy = wv / WX;          // the wave's first row slot
+    const int wi = (wv % WX) / WXW;  // its window
+    int wx0, ty0, sx0;               // the wave's first column, its band's first row, its window's first column
+    if constexpr (SYNTH_PAIR_SEGMENTS && WX > 1 && NWIN == WX) {
+        // one window per wave column: each takes its own 64-column segment (segment_origin)
+        if (!segment_origin<TH, WX>(g, wv % WX, wx0, ty0)) return;
+        sx0 = wx0;
+    } else {
+        int tx0;
+        if (!tile_origin<TH, TW>(g, tx0, ty0)) return;
+        wx0 = tx0 + (wv % WX) * 64;
+        sx0 = tx0 + wi * SW;
+    }
     f32x4 *tile = tile_all + wi * (LH * LW);
     const lds_f32x4 *ltile = (const lds_f32x4 *)tile;
     const int tid = (wy * WXW + (wv % WX) % WXW) * 64 + threadIdx.x;  // thread index among the window's
@@ -1289,8 +1359,14 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
     float res0[ROWS], res1[ROWS], res2[ROWS];  // HEAD: the running sum over frames
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) res0[j] = res1[j] = res2[j] = 0.f;
+    // Reach statistics for ARTEMIS_SYNTH_RADIUS_AUTO (synth_kernels.hip): over the taps of the wave's
+    // FIRST row (a 1 / ROWS sample of the pixels), how many are displaced beyond 8 and beyond 14 whole
+    // pixels from the first window's centre -- low half-word / high half-word (at most 25 x 8 frames
+    // per lane, 12 800 per wave: no carry between the halves).
+    unsigned reach_cnt = 0u;
 
     const int T = HEAD ? ha.T : 1;
+    bool tile_free = true;  // no wave will read the staged windows again before the next barrier
     for (int f = 0; f < T; ++f) {
         size_t pl = plane, rf[ROWS];
 #pragma unroll
@@ -1346,6 +1422,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
                     bool near = reach <= (float)R;
                     if constexpr (FIRST) {
                         fmask[j] |= near ? 0u : 1u << t;
+                        if (j == 0 && R >= 8) reach_cnt += (reach > 8.f ? 1u : 0u) + (reach > 14.f ? 0x10000u : 0u);
                     } else {
                         near = near && ((fmask[j] >> t) & 1u);
                         fmask[j] &= near ? ~(1u << t) : ~0u;
@@ -1368,6 +1445,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
                     // the pixel live (512 VGPRs or spills).  The sched_barrier bounds the LDS results
                     // in flight to kRowGroup rows (16 VGPRs each).
                     asm volatile("" : "+v"(acc0[j]), "+v"(acc1[j]), "+v"(acc2[j]), "+v"(fmask[j]));
+                    if (FIRST && j == 0 && R >= 8) asm volatile("" : "+v"(reach_cnt));
                     if (j % kRowGroup == kRowGroup - 1) __builtin_amdgcn_sched_barrier(0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -1409,8 +1487,9 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
             if (p == 1) dbg_a = wall_clock64();
 #endif
             // every wave is done with the previous window (frame f - 1's last one; within a frame
-            // the vote's barrier has already seen to that)
-            if (HEAD && f > 0 && p == 0) __syncthreads();
+            // the vote's barrier has already seen to that -- and when frame f - 1 ended on a vote
+            // that asked for no further pass, so has that barrier: no wave reads a window after it)
+            if (HEAD && f > 0 && p == 0 && !(SYNTH_HEAD_SYNC_DEDUPE && tile_free)) __syncthreads();
             if (mine)
                 fill_tile_n<R, TH, 64 * (WAVES / NWIN), SW>(tile, ip, g, ty0 + g.oy0 - R + (int)ctr.y,
                                                             sx0 + g.ox0 - R + (int)ctr.x, tid);
@@ -1442,11 +1521,14 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
                 flagged[j] = active ? __ballot(fmask[j] != 0u && owner) : 0ull;
-            if (p + 1 == kMaxPasses) break;
+            tile_free = false;
+            if (p + 1 == PASSES) break;
             Centre next;
             if (!vote_next_window<R, WAVES, ROWS, WX, NWIN>(vote_slot, wv, active, flagged, fmask, rowy, wx0, x,
-                                                            ab, bb, pl, g, win, next, mine))
+                                                            ab, bb, pl, g, win, next, mine)) {
+                tile_free = true;  // (workgroup-uniform: every wave has passed the vote's barrier)
                 break;
+            }
             if (mine) {  // (else another window of the workgroup goes on: only its barriers matter here)
                 if (p == 0) win.c1 = next;
                 else win.c2 = next;
@@ -1503,6 +1585,17 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
         }
     }
     if (!active) return;
+    if (R >= 8 && reach_stats) {  // wave-uniform
+        reach_cnt = owner ? reach_cnt : 0u;
+        if (__ballot(reach_cnt != 0u)) {  // (small offsets: nothing to report, no atomic)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) reach_cnt += (unsigned)__shfl_xor((int)reach_cnt, o);
+            if (threadIdx.x == 0)  // one no-return atomic per wave, spread over kReachSlots addresses
+                __hip_atomic_fetch_add(reach_stats + ((blockIdx.x + wv) & (kReachSlots - 1)),
+                                       (unsigned long long)(reach_cnt >> 16) << 32 | (reach_cnt & 0xffffu),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) {
         float *orow = out + (size_t)n * 3 * plane + roff[j];
@@ -1515,7 +1608,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
         unsigned long long *q =
             g_tile_log + ((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * WAVES + wv) * 12;
         q[0] = dbg_t0, q[1] = dbg_t1, q[2] = dbg_t2, q[3] = wall_clock64();
-        q[4] = dbg_p, q[5] = dbg_left, q[6] = (unsigned long long)(unsigned)tx0 << 32 | (unsigned)ty0;
+        q[4] = dbg_p, q[5] = dbg_left, q[6] = (unsigned long long)(unsigned)sx0 << 32 | (unsigned)ty0;
         q[7] = __smid();
         q[8] = dbg_a, q[9] = dbg_b, q[10] = dbg_c;
     }
@@ -1526,7 +1619,8 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
 // out = sum_f occ_f * S_f; per frame the kernel forms the unscaled tap gradients from it, stores
 // them times occ_f into slice [n, f] of the 5-D gradient tensors in place, and accumulates
 // gocc[n, f] = sum_c gradOutput_c * S_f,c = sum_t w_t * (unscaled gradWeight_t) in registers.
-template <int R, int WAVES, int ROWS, int OCC, bool ALL, bool HEAD, class FT, int WX = 1, int NWIN = 1>
+template <int R, int WAVES, int ROWS, int OCC, bool ALL, bool HEAD, class FT, int WX = 1, int NWIN = 1,
+          int PASSES = kMaxPasses>
 __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
     const FT *__restrict__ in, const float *__restrict__ w, const float *__restrict__ oy,
     const float *__restrict__ ox, const float *__restrict__ gout, float *__restrict__ gw,
@@ -1542,12 +1636,21 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
     static_assert(WX % NWIN == 0, "wave columns must split evenly over the windows");
     __shared__ f32x4 tile_all[NWIN * LH * LW];
     __shared__ float vote_slot[WAVES * kVoteSlots];
-    int tx0, ty0;
-    if (!tile_origin<TH, TW>(g, tx0, ty0)) return;
     const int n = blockIdx.z;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
-    const int wy = wv / WX, wx0 = tx0 + (wv % WX) * 64;  // the wave's first row slot and column
-    const int wi = (wv % WX) / WXW, sx0 = tx0 + wi * SW;  // its window and that window's first column
+    const int wy = wv / WX;          // the wave's first row slot
+    const int wi = (wv % WX) / WXW;  // its window
+    int wx0, ty0, sx0;               // the wave's first column, its band's first row, its window's first column
+    if constexpr (SYNTH_PAIR_SEGMENTS && WX > 1 && NWIN == WX) {
+        // one window per wave column: each takes its own 64-column segment (segment_origin)
+        if (!segment_origin<TH, WX>(g, wv % WX, wx0, ty0)) return;
+        sx0 = wx0;
+    } else {
+        int tx0;
+        if (!tile_origin<TH, TW>(g, tx0, ty0)) return;
+        wx0 = tx0 + (wv % WX) * 64;
+        sx0 = tx0 + wi * SW;
+    }
     f32x4 *tile = tile_all + wi * (LH * LW);
     const lds_f32x4 *ltile = (const lds_f32x4 *)tile;
     const int tid = (wy * WXW + (wv % WX) % WXW) * 64 + threadIdx.x;  // thread index among the window's
@@ -1570,6 +1673,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
     float d[ROWS][3];
 
     const int T = HEAD ? ha.T : 1;
+    bool tile_free = true;  // no wave will read the staged windows again before the next barrier
     for (int f = 0; f < T; ++f) {
         size_t pl = plane, rf[ROWS];
 #pragma unroll
@@ -1731,7 +1835,8 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
             pl = per_frame(pl);  // (see forward)
 #pragma unroll
             for (int j = 0; j < ROWS; ++j) rf[j] = per_frame(rf[j]);
-            if (HEAD && f > 0 && p == 0) __syncthreads();  // every wave is done with the previous window
+            // every wave is done with the previous window (see forward)
+            if (HEAD && f > 0 && p == 0 && !(SYNTH_HEAD_SYNC_DEDUPE && tile_free)) __syncthreads();
             if (mine)
                 fill_tile_n<R, TH, 64 * (WAVES / NWIN), SW>(tile, ip, g, ty0 + g.oy0 - R + (int)ctr.y,
                                                             sx0 + g.ox0 - R + (int)ctr.x, tid);
@@ -1761,11 +1866,14 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
                 flagged[j] = active ? __ballot(fmask[j] != 0u && owner) : 0ull;
-            if (p + 1 == kMaxPasses) break;
+            tile_free = false;
+            if (p + 1 == PASSES) break;
             Centre next;
             if (!vote_next_window<R, WAVES, ROWS, WX, NWIN>(vote_slot, wv, active, flagged, fmask, rowy, wx0, x,
-                                                            ab, bb, pl, g, win, next, mine))
+                                                            ab, bb, pl, g, win, next, mine)) {
+                tile_free = true;  // (workgroup-uniform: every wave has passed the vote's barrier)
                 break;
+            }
             if (mine) {  // (else another window of the workgroup goes on: only its barriers matter here)
                 if (p == 0) win.c1 = next;
                 else win.c2 = next;
@@ -1784,6 +1892,10 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
             unsigned long long todo = __ballot(fmask[j] != 0u && owner);
             if (todo) {  // wave-uniform, rare
                 if (__popcll(todo) <= kCoopMaxPixels) {
+                    // lane l < 25 overwrites what the pixel's OWN lane stored for tap l in the first
+                    // pass: stores of different lanes of a wave are ordered only once the earlier ones
+                    // have been acknowledged
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     while (todo) {
                         const int b = __ffsll((long long)todo) - 1;
                         todo &= todo - 1;

@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <mutex>
 
 #include "synth_device.hpp"
 
@@ -88,13 +89,17 @@ constexpr int kDefaultRadius = SYNTH_DEFAULT_RADIUS;
 int pick_radius(int requested)
 {
     if (requested == ARTEMIS_SYNTH_RADIUS_NONE) return 0;
-    if (requested < 0) requested = kDefaultRadius;
+    if (requested == ARTEMIS_SYNTH_RADIUS_SMALL) return 8;  // (+ the lean shape: is_lean)
+    if (requested < 0) requested = kDefaultRadius;  // (AUTO on a shape without LDS kernels included)
     if (requested <= 2) return 2;
     if (requested <= 4) return 4;
     if (requested <= 8) return 8;
     if (requested <= 14) return 14;
     return 24;
 }
+
+// RADIUS_SMALL: radius 8 in the lean shape (one window per tile, staged once; synth_tiles.hip LeanCfg)
+bool is_lean(int requested) { return requested == ARTEMIS_SYNTH_RADIUS_SMALL; }
 
 // gradInput's 64-bit accumulator window does not fit the LDS beyond R = 14
 int gin_radius(int requested)
@@ -170,97 +175,301 @@ constexpr bool kSmallRadiiBuilt = std::is_same<FT, float>::value;
 
 template <class FT>
 void dispatch_fwd_tiled(int R, const void *input, const float *weight, const float *offset_y,
-                               const float *offset_x, float *output, const Geom &g, hipStream_t st)
+                               const float *offset_x, float *output, const Geom &g, bool lean,
+                               unsigned long long *stats, hipStream_t st)
 {
     const FT *in = (const FT *)input;
     switch (R) {
     case 2:
         if constexpr (kSmallRadiiBuilt<FT>) {
-            launch_fwd_tiled<2, FT>(in, weight, offset_y, offset_x, output, g, st);
+            launch_fwd_tiled<2, FT>(in, weight, offset_y, offset_x, output, g, lean, stats, st);
             break;
         }
         [[fallthrough]];
     case 4:
         if constexpr (kSmallRadiiBuilt<FT>) {
-            launch_fwd_tiled<4, FT>(in, weight, offset_y, offset_x, output, g, st);
+            launch_fwd_tiled<4, FT>(in, weight, offset_y, offset_x, output, g, lean, stats, st);
             break;
         }
         [[fallthrough]];
-    case 8: launch_fwd_tiled<8, FT>(in, weight, offset_y, offset_x, output, g, st); break;
-    case 24: launch_fwd_tiled<24, FT>(in, weight, offset_y, offset_x, output, g, st); break;
-    default: launch_fwd_tiled<14, FT>(in, weight, offset_y, offset_x, output, g, st); break;
+    case 8: launch_fwd_tiled<8, FT>(in, weight, offset_y, offset_x, output, g, lean, stats, st); break;
+    case 24: launch_fwd_tiled<24, FT>(in, weight, offset_y, offset_x, output, g, lean, stats, st); break;
+    default: launch_fwd_tiled<14, FT>(in, weight, offset_y, offset_x, output, g, lean, stats, st); break;
     }
 }
 
 template <class FT>
 void dispatch_bwd_tiled(int R, const void *input, const float *weight, const float *offset_y,
                                const float *offset_x, const float *grad_output, float *gw, float *goy,
-                               float *gox, const Geom &g, hipStream_t st)
+                               float *gox, const Geom &g, bool lean, hipStream_t st)
 {
     const FT *in = (const FT *)input;
     switch (R) {
     case 2:
         if constexpr (kSmallRadiiBuilt<FT>) {
-            launch_bwd_tiled<2, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, st);
+            launch_bwd_tiled<2, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, lean, st);
             break;
         }
         [[fallthrough]];
     case 4:
         if constexpr (kSmallRadiiBuilt<FT>) {
-            launch_bwd_tiled<4, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, st);
+            launch_bwd_tiled<4, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, lean, st);
             break;
         }
         [[fallthrough]];
-    case 8: launch_bwd_tiled<8, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, st); break;
-    case 24: launch_bwd_tiled<24, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, st); break;
-    default: launch_bwd_tiled<14, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, st); break;
+    case 8: launch_bwd_tiled<8, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, lean, st); break;
+    case 24: launch_bwd_tiled<24, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, lean, st); break;
+    default: launch_bwd_tiled<14, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, lean, st); break;
     }
 }
 
 template <class FT>
 void dispatch_head_fwd(int R, const float *w, const float *oy, const float *ox, float *out,
-                              const Geom &g, const HeadArgs &ha, hipStream_t st)
+                              const Geom &g, const HeadArgs &ha, bool lean, unsigned long long *stats,
+                              hipStream_t st)
 {
     switch (R) {
     case 2:
         if constexpr (kSmallRadiiBuilt<FT>) {
-            launch_head_fwd<2, FT>(w, oy, ox, out, g, ha, st);
+            launch_head_fwd<2, FT>(w, oy, ox, out, g, ha, lean, stats, st);
             break;
         }
         [[fallthrough]];
     case 4:
         if constexpr (kSmallRadiiBuilt<FT>) {
-            launch_head_fwd<4, FT>(w, oy, ox, out, g, ha, st);
+            launch_head_fwd<4, FT>(w, oy, ox, out, g, ha, lean, stats, st);
             break;
         }
         [[fallthrough]];
-    case 8: launch_head_fwd<8, FT>(w, oy, ox, out, g, ha, st); break;
-    case 24: launch_head_fwd<24, FT>(w, oy, ox, out, g, ha, st); break;
-    default: launch_head_fwd<14, FT>(w, oy, ox, out, g, ha, st); break;
+    case 8: launch_head_fwd<8, FT>(w, oy, ox, out, g, ha, lean, stats, st); break;
+    case 24: launch_head_fwd<24, FT>(w, oy, ox, out, g, ha, lean, stats, st); break;
+    default: launch_head_fwd<14, FT>(w, oy, ox, out, g, ha, lean, stats, st); break;
     }
 }
 
 template <class FT>
 void dispatch_head_bwd(int R, const float *w, const float *oy, const float *ox,
                               const float *gout, float *gw, float *goy, float *gox, const Geom &g,
-                              const HeadArgs &ha, hipStream_t st)
+                              const HeadArgs &ha, bool lean, hipStream_t st)
 {
     switch (R) {
     case 2:
         if constexpr (kSmallRadiiBuilt<FT>) {
-            launch_head_bwd<2, FT>(w, oy, ox, gout, gw, goy, gox, g, ha, st);
+            launch_head_bwd<2, FT>(w, oy, ox, gout, gw, goy, gox, g, ha, lean, st);
             break;
         }
         [[fallthrough]];
     case 4:
         if constexpr (kSmallRadiiBuilt<FT>) {
-            launch_head_bwd<4, FT>(w, oy, ox, gout, gw, goy, gox, g, ha, st);
+            launch_head_bwd<4, FT>(w, oy, ox, gout, gw, goy, gox, g, ha, lean, st);
             break;
         }
         [[fallthrough]];
-    case 8: launch_head_bwd<8, FT>(w, oy, ox, gout, gw, goy, gox, g, ha, st); break;
-    case 24: launch_head_bwd<24, FT>(w, oy, ox, gout, gw, goy, gox, g, ha, st); break;
-    default: launch_head_bwd<14, FT>(w, oy, ox, gout, gw, goy, gox, g, ha, st); break;
+    case 8: launch_head_bwd<8, FT>(w, oy, ox, gout, gw, goy, gox, g, ha, lean, st); break;
+    case 24: launch_head_bwd<24, FT>(w, oy, ox, gout, gw, goy, gox, g, ha, lean, st); break;
+    default: launch_head_bwd<14, FT>(w, oy, ox, gout, gw, goy, gox, g, ha, lean, st); break;
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// ARTEMIS_SYNTH_RADIUS_AUTO: the library picks 8, 14 or 24 per (device, H, W, op | head) from what
+// the FORWARD kernels saw on their previous launches -- no host synchronisation anywhere.
+//   device side  the forward kernels count, over a 1/ROWS sample of the pixels, the taps displaced
+//                beyond 8 and beyond 14 whole pixels from their window's centre (synth_device.hpp,
+//                reach_cnt) and add the counts, one no-return atomic per wave that has any, to the
+//                key's record in `artemis_synth_auto_counters`;
+//   publish      every few AUTO forward launches a one-wave kernel behind the launch sums the record,
+//                clears it and stores {counts, sequence number} into a pinned host mirror;
+//   host side    the next AUTO call (forward, backward or head) reads the mirror -- plain loads of
+//                host memory -- and moves the key's radius: the smallest of 8 / 14 / 24 that leaves
+//                fewer than kAutoFrac8 (8) / kAutoFrac14 (14) of the taps to the global fix-up, with
+//                a factor-two margin before it goes back down.
+// Any radius is correct for any offsets, so a stale or torn reading costs time, never results
+// (bits may differ at rounding level between radii, like between any two tile_radius values).
+// ------------------------------------------------------------------------------------------
+constexpr int kAutoKeys = 16;
+constexpr double kAutoFrac8 = 5.0e-5;    // taps beyond 8 px that make radius 14 the better shape
+constexpr double kAutoFrac14 = 1.5e-4;   // taps beyond 14 px that make radius 24 the better shape
+constexpr double kAutoMinSamples = 5.0e4;
+
+struct AutoMirror {  // one per key, in pinned host memory the GPU can write
+    unsigned long long seq, c8, c14, pad;
+};
+
+struct AutoEntry {
+    bool used;
+    int H, W, kind;             // kind 0: per-frame op, 1: fused head
+    int radius;
+    unsigned long long calls;   // AUTO forward launches so far
+    unsigned long long seq;     // publishes enqueued
+    unsigned long long seen;    // last publish applied
+    double pending;             // sampled taps launched since the last publish
+    double window[8];           // sampled taps covered by publish `seq` (index seq % 8)
+    double f8, f14;             // fractions of the last publish applied
+};
+
+struct AutoDevice {
+    int state;  // 0 untried, 1 ready, -1 unavailable (allocation failed: AUTO = the default radius)
+    unsigned long long *counters;  // device: kAutoKeys x kReachSlots
+    AutoMirror *mirror;            // host view
+    AutoMirror *mirror_dev;        // the same memory as the GPU addresses it
+    AutoEntry e[kAutoKeys];
+};
+}  // namespace
+
+// (external linkage and `used`: host code reaches it through hipGetSymbolAddress only; as a `static`
+// variable it stayed local to the code object and the lookup aborted inside the HIP runtime)
+__device__ __align__(256) __attribute__((used)) unsigned long long
+    artemis_synth_auto_counters[kAutoKeys * kReachSlots];
+
+namespace {
+constexpr int kMaxDevices = 64;
+AutoDevice g_auto[kMaxDevices];
+std::mutex g_auto_mutex;
+
+__global__ void reach_publish_kernel(unsigned long long *rec, AutoMirror *mirror, unsigned long long seq)
+{
+    unsigned long long v = 0;
+    if (threadIdx.x < kReachSlots) v = atomicExch(rec + threadIdx.x, 0ull);
+    unsigned long long lo = v & 0xffffffffull, hi = v >> 32;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo += (unsigned long long)__shfl_xor((long long)lo, o);
+        hi += (unsigned long long)__shfl_xor((long long)hi, o);
+    }
+    if (threadIdx.x == 0) {
+        volatile AutoMirror *m = mirror;
+        m->c8 = lo;
+        m->c14 = hi;
+        __threadfence_system();
+        m->seq = seq;
+    }
+}
+
+int auto_decide(int cur, double f8, double f14)
+{
+    // 8 stands for ARTEMIS_SYNTH_RADIUS_SMALL: radius 8 in the lean shape (auto_request)
+    auto want_for = [&](double margin) {
+        return f8 <= kAutoFrac8 * margin ? 8 : (f14 <= kAutoFrac14 * margin ? 14 : 24);
+    };
+    int want = want_for(1.0);
+    if (want < cur) {  // going down needs a margin, so that a borderline workload does not flap
+        const int safe = want_for(0.5);
+        want = safe < cur ? safe : cur;
+    }
+    return want;
+}
+
+// the current device's record, set up on first use (the only allocation the library ever makes:
+// 512 bytes of pinned host memory per device; it fails inside a stream capture, so make the first
+// AUTO forward call on a device outside one).  nullptr: unavailable.  Caller holds g_auto_mutex.
+AutoDevice *auto_device(bool may_allocate)
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+    AutoDevice &d = g_auto[dev];
+    if (d.state == 0 && may_allocate) {
+        d.state = -1;
+        void *sym = nullptr, *host = nullptr, *hdev = nullptr;
+        if (hipGetSymbolAddress(&sym, HIP_SYMBOL(artemis_synth_auto_counters)) == hipSuccess && sym &&
+            hipHostMalloc(&host, kAutoKeys * sizeof(AutoMirror), hipHostMallocMapped) == hipSuccess && host) {
+            memset(host, 0, kAutoKeys * sizeof(AutoMirror));
+            if (hipHostGetDevicePointer(&hdev, host, 0) == hipSuccess && hdev) {
+                d.counters = (unsigned long long *)sym;
+                d.mirror = (AutoMirror *)host;
+                d.mirror_dev = (AutoMirror *)hdev;
+                d.state = 1;
+            } else {
+                (void)hipHostFree(host);
+            }
+        }
+        (void)hipGetLastError();  // a failure here is not the caller's launch error
+    }
+    return d.state == 1 ? &d : nullptr;
+}
+
+int auto_find(AutoDevice &d, int H, int W, int kind, bool create)
+{
+    int free_slot = -1;
+    for (int i = 0; i < kAutoKeys; ++i) {
+        if (d.e[i].used && d.e[i].H == H && d.e[i].W == W && d.e[i].kind == kind) return i;
+        if (!d.e[i].used && free_slot < 0) free_slot = i;
+    }
+    if (!create || free_slot < 0) return -1;  // (table full: the shape runs at the default radius)
+    AutoEntry &e = d.e[free_slot];
+    e = AutoEntry{};
+    e.used = true;
+    e.H = H, e.W = W, e.kind = kind;
+    e.radius = kDefaultRadius;
+    // publishes of an earlier user of this slot (artemis_synth_auto_reset) must not count
+    e.seq = e.seen = ((volatile AutoMirror *)d.mirror)[free_slot].seq;
+    return free_slot;
+}
+
+// apply what the GPU has published for entry i since the last look
+void auto_absorb(AutoDevice &d, int i)
+{
+    AutoEntry &e = d.e[i];
+    volatile AutoMirror *m = d.mirror + i;
+    const unsigned long long seq = m->seq;
+    if (seq <= e.seen || seq > e.seq) return;
+    std::atomic_thread_fence(std::memory_order_acquire);
+    const double c8 = (double)m->c8, c14 = (double)m->c14;
+    // a publish sums AND clears the record, so the mirror holds the counts of window `seq` alone
+    // (with more than 8 publishes in flight the ring entry may be a newer window's: an estimate)
+    const double total = e.window[seq % 8];
+    e.seen = seq;
+    if (total < kAutoMinSamples) return;
+    e.f8 = c8 / total;
+    e.f14 = c14 / total;
+    e.radius = auto_decide(e.radius, e.f8, e.f14);
+}
+
+// the tile_radius request an AUTO entry's radius stands for
+int auto_request(int radius) { return radius == 8 ? ARTEMIS_SYNTH_RADIUS_SMALL : radius; }
+
+struct AutoLaunch {
+    int radius;
+    unsigned long long *stats;  // the forward kernel's record, or null
+    int dev, key;
+};
+
+// Radius (and, for a forward launch, the statistics record) of an AUTO call.
+AutoLaunch auto_begin(const Geom &g, int kind, bool forward)
+{
+    AutoLaunch a{kDefaultRadius, nullptr, -1, -1};
+    std::lock_guard<std::mutex> lock(g_auto_mutex);
+    AutoDevice *d = auto_device(forward);
+    if (!d) return a;
+    const int i = auto_find(*d, g.H, g.W, kind, forward);
+    if (i < 0) return a;
+    auto_absorb(*d, i);
+    a.radius = auto_request(d->e[i].radius);
+    if (forward) {
+        a.stats = d->counters + (size_t)i * kReachSlots;
+        a.dev = (int)(d - g_auto);
+        a.key = i;
+    }
+    return a;
+}
+
+// after the forward launch: account its sampled taps and, every few launches, publish
+void auto_end(const AutoLaunch &a, const Geom &g, int frames, hipStream_t st)
+{
+    if (!a.stats) return;
+    std::lock_guard<std::mutex> lock(g_auto_mutex);
+    AutoDevice &d = g_auto[a.dev];
+    AutoEntry &e = d.e[a.key];
+    // one row in four of every wave is sampled (one in two on small grids: those fractions read high)
+    e.pending += 0.25 * 25.0 * (double)frames * (double)g.N * (double)g.H * (double)g.W;
+    e.calls += 1;
+    if (e.calls <= 8 || e.calls % 8 == 0) {
+        e.seq += 1;
+        e.window[e.seq % 8] = e.pending;
+        e.pending = 0.0;
+        hipLaunchKernelGGL(reach_publish_kernel, dim3(1), dim3(64), 0, st,
+                           d.counters + (size_t)a.key * kReachSlots, d.mirror_dev + a.key, e.seq);
     }
 }
 
@@ -285,12 +494,21 @@ static int run_forward(const Geom &g, int rc, const void *input_any, const float
     if (!input_any || !weight || !offset_y || !offset_x || !output)
         return fail(hipErrorInvalidValue, "artemis_synth_forward: NULL tensor pointer");
     hipStream_t st = (hipStream_t)stream;
+    AutoLaunch au{0, nullptr, -1, -1};
+    if (tile_radius == ARTEMIS_SYNTH_RADIUS_AUTO && tiled_ok(g)) {
+        au = auto_begin(g, 0, true);
+        tile_radius = au.radius;
+    }
     const int R = tiled_radius(g, tile_radius, frame_dtype);
+    const bool lean = is_lean(tile_radius);
     if (R > 0) {
         if (frame_dtype == ARTEMIS_SYNTH_FRAME_BF16)
-            dispatch_fwd_tiled<asynth::bf16_t>(R, input_any, weight, offset_y, offset_x, output, g, st);
+            dispatch_fwd_tiled<asynth::bf16_t>(R, input_any, weight, offset_y, offset_x, output, g, lean,
+                                               au.stats, st);
         else
-            dispatch_fwd_tiled<float>(R, input_any, weight, offset_y, offset_x, output, g, st);
+            dispatch_fwd_tiled<float>(R, input_any, weight, offset_y, offset_x, output, g, lean, au.stats,
+                                      st);
+        auto_end(au, g, 1, st);
     } else {
         const float *input = (const float *)input_any;
         for (int c0 = 0; c0 < g.C; c0 += 4) {
@@ -365,16 +583,19 @@ static int run_backward(const Geom &g, int rc, const void *input_any, const floa
     }
     if (!input || !weight || !offset_y || !offset_x || !grad_output)
         return fail(hipErrorInvalidValue, "artemis_synth_backward: NULL tensor pointer");
+    // AUTO: the radius the forward launches of this shape have settled on (no statistics here)
+    if (tile_radius == ARTEMIS_SYNTH_RADIUS_AUTO && tiled_ok(g)) tile_radius = auto_begin(g, 0, false).radius;
 
     if (grad_weight || grad_offset_y || grad_offset_x) {
         const int R = tiled_radius(g, tile_radius, frame_dtype);
+        const bool lean = is_lean(tile_radius);
         if (R > 0) {
             if (frame_dtype == ARTEMIS_SYNTH_FRAME_BF16)
                 dispatch_bwd_tiled<asynth::bf16_t>(R, input_any, weight, offset_y, offset_x, grad_output,
-                                                   grad_weight, grad_offset_y, grad_offset_x, g, st);
+                                                   grad_weight, grad_offset_y, grad_offset_x, g, lean, st);
             else
                 dispatch_bwd_tiled<float>(R, input_any, weight, offset_y, offset_x, grad_output,
-                                          grad_weight, grad_offset_y, grad_offset_x, g, st);
+                                          grad_weight, grad_offset_y, grad_offset_x, g, lean, st);
         } else {
             if (k == 5 && C == 3)
                 hipLaunchKernelGGL((synth_bwd_direct<3, 5>), pixel_grid(g, 4), dim3(64, 4), 0, st, input,
@@ -492,7 +713,6 @@ static __device__ __align__(256) __attribute__((used)) unsigned char
     scratch[ARTEMIS_SYNTH_NOALLOC_SCRATCH_BYTES];
 
 namespace {
-constexpr int kMaxDevices = 64;
 std::atomic<void *> g_scratch_ptr[kMaxDevices];  // per device; racing first calls store one value
 
 int scratch_for_current_device(void **out)
@@ -527,10 +747,16 @@ int artemis_synth_backward_noalloc(const void *input, const float *weight, const
     const int rc = make_geom_ex(g, N, C, H, W, k, d, in_H, in_W, org_y, org_x);
     void *ws = nullptr;
     size_t ws_bytes = 0;
-    if (rc == 0 && grad_input &&
-        (gin_mode == ARTEMIS_SYNTH_GIN_ATOMIC || gin_mode == ARTEMIS_SYNTH_GIN_DETERMINISTIC)) {
-        // the bound that holds for every tile_radius, as the size query reports it
-        const size_t need = ws_bytes_needed(g, gin_mode, tiled_ok(g) ? 1 : 0);
+    // argument errors first, so that they read as artemis_synth_backward_ex reports them
+    if (rc > 0) return rc;
+    if (const int e = check_frame_dtype(g, frame_dtype, "artemis_synth_backward")) return e;
+    if (gin_mode != ARTEMIS_SYNTH_GIN_ATOMIC && gin_mode != ARTEMIS_SYNTH_GIN_DETERMINISTIC)
+        return fail(hipErrorInvalidValue, "artemis_synth_backward: unknown gin_mode %d", gin_mode);
+    if (rc == 0 && grad_input) {
+        // what run_backward will ask for at this tile_radius (ATOMIC with RADIUS_NONE needs nothing
+        // and never touches -- or resolves -- the array); AUTO resolves to a radius of at most 24
+        const int Rg = tiled_ok(g) ? (tile_radius == ARTEMIS_SYNTH_RADIUS_AUTO ? 1 : gin_radius(tile_radius)) : 0;
+        const size_t need = ws_bytes_needed(g, gin_mode, Rg);
         if (need > (size_t)ARTEMIS_SYNTH_NOALLOC_SCRATCH_BYTES)
             return fail(hipErrorInvalidValue,
                         "artemis_synth_backward_noalloc: grad_input of %lld elements in this gin_mode "
@@ -551,7 +777,8 @@ int artemis_synth_backward_noalloc(const void *input, const float *weight, const
 // ---- fused ChronoSynth head ----------------------------------------------------------------
 static int head_setup(Geom &g, HeadArgs &ha, const char *what, const void *const *frames, int T,
                       const float *occlusion, int B, int H, int W, int in_H, int in_W, int org_y,
-                      int org_x, int frame_dtype, int tile_radius, int &R)
+                      int org_x, int frame_dtype, int tile_radius, int &R, bool &lean, bool forward,
+                      AutoLaunch &au)
 {
     if (T < 1 || T > kMaxFrames)
         return fail(hipErrorInvalidValue, "%s: T=%d context frames (1..%d supported)", what, T,
@@ -569,7 +796,13 @@ static int head_setup(Geom &g, HeadArgs &ha, const char *what, const void *const
     ha.occ = occlusion;
     ha.T = T;
     if (const int e = check_frame_dtype(g, frame_dtype, what)) return e;
+    au = AutoLaunch{0, nullptr, -1, -1};
+    if (tile_radius == ARTEMIS_SYNTH_RADIUS_AUTO) {
+        au = auto_begin(g, 1, forward);
+        tile_radius = au.radius;
+    }
     R = pick_radius(tile_radius);
+    lean = is_lean(tile_radius);
     if (R == 0) R = pick_radius(ARTEMIS_SYNTH_RADIUS_DEFAULT);  // the head has no direct variant
     if (R < 8 && frame_dtype == ARTEMIS_SYNTH_FRAME_BF16) R = 8;  // (smallest radius built for bf16)
     return 0;
@@ -584,17 +817,20 @@ int artemis_synth_head_forward(const void *const *frames, int T, const float *we
     Geom g;
     HeadArgs ha;
     int R = 0;
+    bool lean = false;
+    AutoLaunch au;
     const int rc = head_setup(g, ha, "artemis_synth_head_forward", frames, T, occlusion, B, H, W, in_H,
-                              in_W, org_y, org_x, frame_dtype, tile_radius, R);
+                              in_W, org_y, org_x, frame_dtype, tile_radius, R, lean, true, au);
     if (rc > 0) return rc;
     if (rc < 0) return 0;
     if (!weights || !offsets_y || !offsets_x || !output)
         return fail(hipErrorInvalidValue, "artemis_synth_head_forward: NULL tensor pointer");
     hipStream_t st = (hipStream_t)stream;
     if (frame_dtype == ARTEMIS_SYNTH_FRAME_BF16)
-        dispatch_head_fwd<asynth::bf16_t>(R, weights, offsets_y, offsets_x, output, g, ha, st);
+        dispatch_head_fwd<asynth::bf16_t>(R, weights, offsets_y, offsets_x, output, g, ha, lean, au.stats, st);
     else
-        dispatch_head_fwd<float>(R, weights, offsets_y, offsets_x, output, g, ha, st);
+        dispatch_head_fwd<float>(R, weights, offsets_y, offsets_x, output, g, ha, lean, au.stats, st);
+    auto_end(au, g, T, st);
     return check_launch("artemis_synth_head_forward");
 }
 
@@ -608,8 +844,10 @@ int artemis_synth_head_backward(const void *const *frames, int T, const float *w
     Geom g;
     HeadArgs ha;
     int R = 0;
+    bool lean = false;
+    AutoLaunch au;
     const int rc = head_setup(g, ha, "artemis_synth_head_backward", frames, T, occlusion, B, H, W,
-                              in_H, in_W, org_y, org_x, frame_dtype, tile_radius, R);
+                              in_H, in_W, org_y, org_x, frame_dtype, tile_radius, R, lean, false, au);
     if (rc > 0) return rc;
     if (rc < 0) return 0;
     if (!weights || !offsets_y || !offsets_x || !grad_output)
@@ -619,11 +857,39 @@ int artemis_synth_head_backward(const void *const *frames, int T, const float *w
     hipStream_t st = (hipStream_t)stream;
     if (frame_dtype == ARTEMIS_SYNTH_FRAME_BF16)
         dispatch_head_bwd<asynth::bf16_t>(R, weights, offsets_y, offsets_x, grad_output, grad_weights,
-                                          grad_offsets_y, grad_offsets_x, g, ha, st);
+                                          grad_offsets_y, grad_offsets_x, g, ha, lean, st);
     else
         dispatch_head_bwd<float>(R, weights, offsets_y, offsets_x, grad_output, grad_weights,
-                                 grad_offsets_y, grad_offsets_x, g, ha, st);
+                                 grad_offsets_y, grad_offsets_x, g, ha, lean, st);
     return check_launch("artemis_synth_head_backward");
+}
+
+int artemis_synth_auto_query(int H, int W, int head, int *radius, double *frac8, double *frac14,
+                             unsigned long long *forward_calls)
+{
+    std::lock_guard<std::mutex> lock(g_auto_mutex);
+    int R = kDefaultRadius;
+    double f8 = 0.0, f14 = 0.0;
+    unsigned long long calls = 0;
+    if (AutoDevice *d = auto_device(false)) {
+        const int i = auto_find(*d, H, W, head ? 1 : 0, false);
+        if (i >= 0) {
+            auto_absorb(*d, i);
+            R = d->e[i].radius, f8 = d->e[i].f8, f14 = d->e[i].f14, calls = d->e[i].calls;
+        }
+    }
+    if (radius) *radius = R;
+    if (frac8) *frac8 = f8;
+    if (frac14) *frac14 = f14;
+    if (forward_calls) *forward_calls = calls;
+    return 0;
+}
+
+void artemis_synth_auto_reset(void)
+{
+    std::lock_guard<std::mutex> lock(g_auto_mutex);
+    if (AutoDevice *d = auto_device(false))
+        for (int i = 0; i < kAutoKeys; ++i) d->e[i].used = false;
 }
 
 long long artemis_synth_set_small_grid_tiles(long long tiles)

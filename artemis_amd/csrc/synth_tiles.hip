@@ -47,7 +47,7 @@ namespace {
 template <int R>
 struct TileCfg {
     static constexpr int WAVES = SYNTH_WAVES, WX = SYNTH_WX, ROWS = SYNTH_ROWS, OCC = SYNTH_OCC,
-                         NWIN = SYNTH_NWIN;
+                         NWIN = SYNTH_NWIN, PASSES = kMaxPasses;
     static constexpr bool kSolo = SYNTH_ONE_WG_PER_CU;
 };
 
@@ -71,7 +71,23 @@ struct BwdCfg {
     // whole 512-register file; with 2 the compiler held the small radii (whose LDS would admit a
     // second workgroup) to 256 registers and spilled 60-240 of them
     static constexpr int WAVES = SYNTH_BWD_WAVES, WX = SYNTH_WX, ROWS = SYNTH_BWD_ROWS, OCC = 1,
-                         NWIN = SYNTH_NWIN;
+                         NWIN = SYNTH_NWIN, PASSES = kMaxPasses;
+    static constexpr bool kSolo = true;
+};
+
+// The LEAN shape (tile_radius ARTEMIS_SYNTH_RADIUS_SMALL; what ARTEMIS_SYNTH_RADIUS_AUTO runs once the
+// forward kernels have seen practically no tap beyond 8 px of its window's centre): radius 8, the same
+// 128 x 16 tile served by ONE 128-column window staged once -- no per-64-column centres, no vote, no
+// further windows; a stray tap still takes the per-pixel global fix-up, so any offsets are correct.
+// It is round 1's kernel shape: the windows-follow-the-motion machinery costs the i.i.d. small-offset
+// regimes 2-5 % on the per-frame kernels and 15-20 % on the fused head's forward (1080p, sigma 1, head
+// forward: 466 us with it, 441 without the vote, 392 in round 1), which this shape gives back.
+struct LeanCfg {
+    static constexpr int WAVES = 8, WX = 2, ROWS = 4, OCC = 2, NWIN = 1, PASSES = 1;
+    static constexpr bool kSolo = true;
+};
+struct LeanBwdCfg {
+    static constexpr int WAVES = 4, WX = 2, ROWS = 8, OCC = 1, NWIN = 1, PASSES = 1;
     static constexpr bool kSolo = true;
 };
 
@@ -84,17 +100,17 @@ struct BwdCfg {
 // steep flow.)
 template <>
 struct TileCfg<24> {
-    static constexpr int WAVES = 8, WX = 1, ROWS = 4, OCC = 2, NWIN = 1;
+    static constexpr int WAVES = 8, WX = 1, ROWS = 4, OCC = 2, NWIN = 1, PASSES = kMaxPasses;
     static constexpr bool kSolo = false;
 };
 template <>
 struct BwdCfg<24> {
-    static constexpr int WAVES = 8, WX = 1, ROWS = 4, OCC = 2, NWIN = 1;
+    static constexpr int WAVES = 8, WX = 1, ROWS = 4, OCC = 2, NWIN = 1, PASSES = kMaxPasses;
     static constexpr bool kSolo = false;
 };
 
 struct SmallCfg {
-    static constexpr int WAVES = 4, WX = 1, ROWS = 2, OCC = 2, NWIN = 1;
+    static constexpr int WAVES = 4, WX = 1, ROWS = 2, OCC = 2, NWIN = 1, PASSES = kMaxPasses;
     static constexpr bool kSolo = false;
 };
 
@@ -119,18 +135,27 @@ bool small_grid(const asynth::Geom &g, bool backward)
     return tiles < (backward ? knob : (knob + 3) / 4);
 }
 
+// workgroups of a config: whole tiles, or (SYNTH_PAIR_SEGMENTS builds, one staged window per wave
+// column) the paired-segment mapping of segment_origin
+template <class T>
+dim3 cfg_grid(const asynth::Geom &g)
+{
+    return asynth::tile_grid(g, (T::WAVES / T::WX) * T::ROWS, 64 * T::WX,
+                             (SYNTH_PAIR_SEGMENTS && T::WX > 1 && T::NWIN == T::WX) ? T::WX : 1);
+}
+
 template <int R, class T, class FT>
 void fwd_cfg(bool head, const FT *in, const float *w, const float *oy, const float *ox, float *out,
-             const asynth::Geom &g, const asynth::HeadArgs &ha, hipStream_t st)
+             const asynth::Geom &g, const asynth::HeadArgs &ha, unsigned long long *stats, hipStream_t st)
 {
-    const dim3 grid = asynth::tile_grid(g, (T::WAVES / T::WX) * T::ROWS, 64 * T::WX), block(64, T::WAVES);
+    const dim3 grid = cfg_grid<T>(g), block(64, T::WAVES);
     const unsigned pad = lds_pad<R, T>();
     if (head)
-        hipLaunchKernelGGL((synth_fwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true, FT, T::WX, T::NWIN>), grid, block,
-                           pad, st, in, w, oy, ox, out, g, ha);
+        hipLaunchKernelGGL((synth_fwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true, FT, T::WX, T::NWIN, T::PASSES>), grid, block,
+                           pad, st, in, w, oy, ox, out, g, ha, stats);
     else
-        hipLaunchKernelGGL((synth_fwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false, FT, T::WX, T::NWIN>), grid, block,
-                           pad, st, in, w, oy, ox, out, g, ha);
+        hipLaunchKernelGGL((synth_fwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false, FT, T::WX, T::NWIN, T::PASSES>), grid, block,
+                           pad, st, in, w, oy, ox, out, g, ha, stats);
 }
 
 template <int R, class T, class FT>
@@ -138,22 +163,22 @@ void bwd_cfg(bool head, const FT *in, const float *w, const float *oy, const flo
              const float *gout, float *gw, float *goy, float *gox, const asynth::Geom &g,
              const asynth::HeadArgs &ha, hipStream_t st)
 {
-    const dim3 grid = asynth::tile_grid(g, (T::WAVES / T::WX) * T::ROWS, 64 * T::WX), block(64, T::WAVES);
+    const dim3 grid = cfg_grid<T>(g), block(64, T::WAVES);
     const unsigned pad = lds_pad<R, T>();
     const bool all = gw && goy && gox;
     if (head) {
         if (all)
-            hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true, true, FT, T::WX, T::NWIN>), grid,
+            hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true, true, FT, T::WX, T::NWIN, T::PASSES>), grid,
                                block, pad, st, in, w, oy, ox, gout, gw, goy, gox, g, ha);
         else
-            hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false, true, FT, T::WX, T::NWIN>), grid,
+            hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false, true, FT, T::WX, T::NWIN, T::PASSES>), grid,
                                block, pad, st, in, w, oy, ox, gout, gw, goy, gox, g, ha);
     } else {
         if (all)
-            hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true, false, FT, T::WX, T::NWIN>), grid,
+            hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true, false, FT, T::WX, T::NWIN, T::PASSES>), grid,
                                block, pad, st, in, w, oy, ox, gout, gw, goy, gox, g, ha);
         else
-            hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false, false, FT, T::WX, T::NWIN>), grid,
+            hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false, false, FT, T::WX, T::NWIN, T::PASSES>), grid,
                                block, pad, st, in, w, oy, ox, gout, gw, goy, gox, g, ha);
     }
 }
@@ -164,39 +189,71 @@ namespace asynth {
 
 template <int R, class FT>
 void launch_fwd_tiled(const FT *in, const float *w, const float *oy, const float *ox, float *out,
-                      const Geom &g, hipStream_t st)
+                      const Geom &g, bool lean, unsigned long long *stats, hipStream_t st)
 {
-    if (small_grid<TileCfg<R>>(g, false)) fwd_cfg<R, SmallCfg, FT>(false, in, w, oy, ox, out, g, HeadArgs{}, st);
-    else fwd_cfg<R, TileCfg<R>, FT>(false, in, w, oy, ox, out, g, HeadArgs{}, st);
+    if (small_grid<TileCfg<R>>(g, false)) {
+        fwd_cfg<R, SmallCfg, FT>(false, in, w, oy, ox, out, g, HeadArgs{}, stats, st);
+        return;
+    }
+    if constexpr (R == 8) {  // (the lean shape is built for radius 8 only)
+        if (lean) {
+            fwd_cfg<R, LeanCfg, FT>(false, in, w, oy, ox, out, g, HeadArgs{}, stats, st);
+            return;
+        }
+    }
+    fwd_cfg<R, TileCfg<R>, FT>(false, in, w, oy, ox, out, g, HeadArgs{}, stats, st);
 }
 
 template <int R, class FT>
 void launch_bwd_tiled(const FT *in, const float *w, const float *oy, const float *ox,
-                      const float *gout, float *gw, float *goy, float *gox, const Geom &g,
+                      const float *gout, float *gw, float *goy, float *gox, const Geom &g, bool lean,
                       hipStream_t st)
 {
-    if (small_grid<TileCfg<R>>(g, true))
+    if (small_grid<TileCfg<R>>(g, true)) {
         bwd_cfg<R, SmallCfg, FT>(false, in, w, oy, ox, gout, gw, goy, gox, g, HeadArgs{}, st);
-    else
-        bwd_cfg<R, BwdCfg<R>, FT>(false, in, w, oy, ox, gout, gw, goy, gox, g, HeadArgs{}, st);
+        return;
+    }
+    if constexpr (R == 8) {
+        if (lean) {
+            bwd_cfg<R, LeanBwdCfg, FT>(false, in, w, oy, ox, gout, gw, goy, gox, g, HeadArgs{}, st);
+            return;
+        }
+    }
+    bwd_cfg<R, BwdCfg<R>, FT>(false, in, w, oy, ox, gout, gw, goy, gox, g, HeadArgs{}, st);
 }
 
 template <int R, class FT>
 void launch_head_fwd(const float *w, const float *oy, const float *ox, float *out, const Geom &g,
-                     const HeadArgs &ha, hipStream_t st)
+                     const HeadArgs &ha, bool lean, unsigned long long *stats, hipStream_t st)
 {
-    if (small_grid<TileCfg<R>>(g, false)) fwd_cfg<R, SmallCfg, FT>(true, (const FT *)nullptr, w, oy, ox, out, g, ha, st);
-    else fwd_cfg<R, TileCfg<R>, FT>(true, (const FT *)nullptr, w, oy, ox, out, g, ha, st);
+    if (small_grid<TileCfg<R>>(g, false)) {
+        fwd_cfg<R, SmallCfg, FT>(true, (const FT *)nullptr, w, oy, ox, out, g, ha, stats, st);
+        return;
+    }
+    if constexpr (R == 8) {
+        if (lean) {
+            fwd_cfg<R, LeanCfg, FT>(true, (const FT *)nullptr, w, oy, ox, out, g, ha, stats, st);
+            return;
+        }
+    }
+    fwd_cfg<R, TileCfg<R>, FT>(true, (const FT *)nullptr, w, oy, ox, out, g, ha, stats, st);
 }
 
 template <int R, class FT>
 void launch_head_bwd(const float *w, const float *oy, const float *ox, const float *gout, float *gw,
-                     float *goy, float *gox, const Geom &g, const HeadArgs &ha, hipStream_t st)
+                     float *goy, float *gox, const Geom &g, const HeadArgs &ha, bool lean, hipStream_t st)
 {
-    if (small_grid<TileCfg<R>>(g, true))
+    if (small_grid<TileCfg<R>>(g, true)) {
         bwd_cfg<R, SmallCfg, FT>(true, (const FT *)nullptr, w, oy, ox, gout, gw, goy, gox, g, ha, st);
-    else
-        bwd_cfg<R, BwdCfg<R>, FT>(true, (const FT *)nullptr, w, oy, ox, gout, gw, goy, gox, g, ha, st);
+        return;
+    }
+    if constexpr (R == 8) {
+        if (lean) {
+            bwd_cfg<R, LeanBwdCfg, FT>(true, (const FT *)nullptr, w, oy, ox, gout, gw, goy, gox, g, ha, st);
+            return;
+        }
+    }
+    bwd_cfg<R, BwdCfg<R>, FT>(true, (const FT *)nullptr, w, oy, ox, gout, gw, goy, gox, g, ha, st);
 }
 
 // gradInput tiles: 64 x 16 pixels, 64-bit accumulators (3 x 29 x 77 x 8 B = 53.6 KB at R = 4,
@@ -229,18 +286,18 @@ typedef float frame_t;
 #endif
 
 template void launch_fwd_tiled<SYNTH_TILE_R, frame_t>(const frame_t *, const float *, const float *,
-                                                      const float *, float *, const Geom &,
-                                                      hipStream_t);
+                                                      const float *, float *, const Geom &, bool,
+                                                      unsigned long long *, hipStream_t);
 #ifndef SYNTH_DEV_ONLY_FWD  // (developer builds: compile just the forward to look at its registers)
 template void launch_bwd_tiled<SYNTH_TILE_R, frame_t>(const frame_t *, const float *, const float *,
                                                       const float *, const float *, float *, float *,
-                                                      float *, const Geom &, hipStream_t);
+                                                      float *, const Geom &, bool, hipStream_t);
 template void launch_head_fwd<SYNTH_TILE_R, frame_t>(const float *, const float *, const float *,
-                                                     float *, const Geom &, const HeadArgs &,
-                                                     hipStream_t);
+                                                     float *, const Geom &, const HeadArgs &, bool,
+                                                     unsigned long long *, hipStream_t);
 template void launch_head_bwd<SYNTH_TILE_R, frame_t>(const float *, const float *, const float *,
                                                      const float *, float *, float *, float *,
-                                                     const Geom &, const HeadArgs &, hipStream_t);
+                                                     const Geom &, const HeadArgs &, bool, hipStream_t);
 #if !SYNTH_TILE_BF16 && SYNTH_TILE_R <= 14  // (gradInput's 64-bit accumulator window tops out at R = 14)
 template void launch_gin_tiled<SYNTH_TILE_R, false>(const float *, const float *, const float *,
                                                     const float *, float *, unsigned char *,

@@ -12,8 +12,11 @@ the modes that exercise the hot path, Lightning- and CuPy-free, with HIP device 
 Flags keep the reference's names and defaults where the reference has them (config.py:14-63).
 Interpolate mode (main.py:98-124) evaluates ALL timesteps as one batch (``ArTEMIS.interpolate``):
 encoder and decoder once per window, the synthesis heads at N = #timesteps -- upstream runs the whole
-model once per timestep.  Under ``torchrun`` the timesteps are dealt to the ranks
-(``sharding.shard_items``: 7 timesteps on 8 GPUs = one each, one rank idle), no collective.
+model once per timestep.  Under ``torchrun`` WHOLE timesteps are dealt to the ranks
+(``sharding.shard_items``: 7 timesteps on 8 GPUs = one each, one rank idle; 4/3 on 2 GPUs), no
+collective, and every rank runs encoder and decoder for its window.  (The balanced split of one
+window -- a row strip of all timesteps per rank, ``sharding.shard_interpolation`` -- is the
+library- and bench-level path, ``bench.py --workload interp7``; this CLI does not use it.)
 Training data is synthetic (the Vimeo-90K septuplet set, 82 GB, is not part of this repository);
 frames on disk are read with PIL when it is importable.
 """

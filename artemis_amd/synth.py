@@ -37,9 +37,13 @@ from . import _lib
 @dataclass
 class SynthOptions:
     #: displacement radius (whole pixels) served from the LDS-staged frame tile;
-    #: -1 = library default, 0 = no LDS staging (direct gathers).  Any value is correct for any
-    #: offsets: taps displaced farther are recomputed through the direct path.
-    tile_radius: int = _lib.RADIUS_DEFAULT
+    #: -2 = adaptive (the library moves between 8, 14 and 24 per tensor shape from what its forward
+    #: kernels saw on earlier calls: no host synchronisation, include/artemis_synth.h
+    #: ARTEMIS_SYNTH_RADIUS_AUTO), -1 = the fixed library default (14), 0 = no LDS staging (direct
+    #: gathers).  Any value is correct for any offsets: taps displaced farther are recomputed
+    #: through the direct path.  Results of different radii agree to fp32 summation order; with
+    #: ``deterministic`` (or torch.use_deterministic_algorithms) adaptive means the fixed default.
+    tile_radius: int = _lib.RADIUS_AUTO
     #: bit-reproducible gradInput (fixed-point integer accumulation) instead of fp32 atomics
     deterministic: bool = False
 
@@ -105,10 +109,19 @@ def _frame_dtype(t):
     raise TypeError(f"frames must be float32 or bfloat16, got {t.dtype}")
 
 
+def _tile_radius():
+    """options.tile_radius as passed to the library: the adaptive choice depends on the calls made
+    before, so callers who asked for reproducible results get the fixed default instead."""
+    r = int(options.tile_radius)
+    if r == _lib.RADIUS_AUTO and (options.deterministic or torch.are_deterministic_algorithms_enabled()):
+        r = _lib.RADIUS_DEFAULT
+    return r
+
+
 def _capture_options(context):
     """The options in force when the forward runs also govern its backward: autograd calls
     backward later, on its own thread, usually outside any ``with synth_options(...)`` block."""
-    context.synth_tile_radius = int(options.tile_radius)
+    context.synth_tile_radius = _tile_radius()
     context.synth_deterministic = bool(options.deterministic)
 
 
@@ -123,7 +136,7 @@ def _launch_forward(input, weight, offset_y, offset_x, dilation, geom):
         _lib.check(lib.artemis_synth_forward_ex(
             _ptr(input), _ptr(weight), _ptr(offset_y), _ptr(offset_x), _ptr(output),
             N, C, H, W, k, int(dilation), Hin, Win, oy0, ox0, _frame_dtype(input),
-            int(options.tile_radius), stream), "artemis_synth_forward")
+            _tile_radius(), stream), "artemis_synth_forward")
     return output
 
 
@@ -131,7 +144,7 @@ def _launch_backward(need, gradOutput, input, weight, offset_y, offset_x, dilati
                      tile_radius=None, deterministic=None):
     """tile_radius / deterministic: the values captured at forward time (None: current options)."""
     N, C, H, W, k, Hin, Win, oy0, ox0 = geom
-    tile_radius = int(options.tile_radius if tile_radius is None else tile_radius)
+    tile_radius = int(_tile_radius() if tile_radius is None else tile_radius)
     deterministic = bool(options.deterministic if deterministic is None else deterministic)
     assert (gradOutput.is_contiguous() == True)
     if not input.is_cuda:
@@ -315,7 +328,7 @@ class FunctionChronoHead(torch.autograd.Function):
             ptrs = (ctypes.c_void_p * T)(*[f.data_ptr() for f in frames])
             _lib.check(lib.artemis_synth_head_forward(
                 ptrs, T, _ptr(weights), _ptr(alphas), _ptr(betas), _ptr(occlusion), _ptr(out),
-                B, H, W, H + 2 * pad, W + 2 * pad, pad - 2, pad - 2, fdt, int(options.tile_radius),
+                B, H, W, H + 2 * pad, W + 2 * pad, pad - 2, pad - 2, fdt, _tile_radius(),
                 torch.cuda.current_stream().cuda_stream), "artemis_synth_head_forward")
         return out
 
@@ -379,13 +392,24 @@ def offset_radius(offset_y, offset_x) -> torch.Tensor:
 
 
 def suggest_tile_radius(offset_y, offset_x) -> int:
-    """A ``tile_radius`` for offsets like these -- ONE host synchronisation (``.item()``), so call it
-    on a representative batch once, not per step, and set ``options.tile_radius`` from it.  Offsets
-    whose whole-pixel part stays within the default window (14) are served by the default shape,
-    which is the fastest there; anything larger gets 24, the one-window-per-64x32-tile shape that
-    costs 4-6 % on small offsets and wins 8-60 % on large steep or scattered ones.
-    (A large but uniform displacement -- a pan -- would run as fast at the default: the scalar
-    cannot tell it from a steep flow.)"""
+    """A fixed ``tile_radius`` for offsets like these -- ONE host synchronisation (``.item()``) and a
+    pass over both tensors; for callers who want a fixed radius (bit-reproducible forward).  The
+    default ``options.tile_radius`` (adaptive) needs neither.  8 when every whole-pixel offset stays
+    within 8, 14 within 14, else 24.  (A large but uniform displacement -- a pan --
+    would run as fast at 8: the scalar cannot tell it from a steep flow; the adaptive mode can.)"""
     reach = int(offset_radius(offset_y, offset_x).item())
-    return _lib.RADIUS_DEFAULT if reach <= 14 else 24
+    return 8 if reach <= 8 else (14 if reach <= 14 else 24)
+
+
+def adaptive_state(height, width, head=False, device=None):
+    """What the adaptive tile radius currently holds for output size (height, width) of the
+    per-frame op (or the fused head) on ``device``: dict(radius, frac8, frac14, forward_calls).
+    Host-only (artemis_synth_auto_query)."""
+    lib = _lib.load()
+    r, c = ctypes.c_int(0), ctypes.c_ulonglong(0)
+    f8, f14 = ctypes.c_double(0), ctypes.c_double(0)
+    with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+        lib.artemis_synth_auto_query(int(height), int(width), int(bool(head)), ctypes.byref(r),
+                                     ctypes.byref(f8), ctypes.byref(f14), ctypes.byref(c))
+    return {"radius": r.value, "frac8": f8.value, "frac14": f14.value, "forward_calls": c.value}
 

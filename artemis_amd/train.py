@@ -182,7 +182,9 @@ def main(argv=None):
     full = args.model == "artemis"
     tr = (ModelTrainer if full else HeadTrainer)(device, num_features=args.features,
                                                  fused=not args.composed)
+    import time
     for i in range(args.steps * args.epochs):
+        t0 = time.perf_counter()
         if full:
             batch = synthetic_frames(args.batch, (args.size, args.size), 1000 + i, device)
         else:
@@ -196,7 +198,8 @@ def main(argv=None):
             if args.backend != "nccl":
                 loss /= world
         if tr.rank == 0:
-            print(f"step {i}: loss {float(loss):.6f} lr {tr.scheduler.get_last_lr()[0]:.2e}", flush=True)
+            print(f"step {i}: loss {float(loss):.6f} lr {tr.scheduler.get_last_lr()[0]:.2e} "
+                  f"({time.perf_counter() - t0:.3f} s)", flush=True)
     if args.dump and tr.rank == 0:
         torch.save({k: v.detach().cpu() for k, v in tr.module.state_dict().items()}, args.dump)
     if dist_on:

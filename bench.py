@@ -288,6 +288,16 @@ def recorded_traffic(key, batch):
     return (None if v is None else int(v) * batch), "profiles/pmc_traffic.json (rocprofv3 --pmc, recorded)"
 
 
+def adaptive_state(lib, h, w, head=False):
+    """What ARTEMIS_SYNTH_RADIUS_AUTO holds for this shape right now (host-only query)."""
+    r, c = ctypes.c_int(0), ctypes.c_ulonglong(0)
+    f8, f14 = ctypes.c_double(0), ctypes.c_double(0)
+    lib.artemis_synth_auto_query(h, w, int(head), ctypes.byref(r), ctypes.byref(f8), ctypes.byref(f14),
+                                 ctypes.byref(c))
+    return {"radius": r.value, "taps_beyond_8px": f8.value, "taps_beyond_14px": f14.value,
+            "forward_calls": c.value}
+
+
 class Op:
     """fwd / bwd launchers of one operand set list through the C ABI."""
 
@@ -332,8 +342,10 @@ def regime_timing(lib, device, B, radius, stream, regime, steps, headline_mpix):
         radius = int(r)
     frames = make_frames(B, 0.0, device, seed=211, regime=regime)
     op = Op(lib, frames, B, radius, stream)
-    for _ in range(2):
+    for _ in range(2):          # (the adaptive radius follows the new offsets with the lag of the
+        op.step()               # launches in flight: let two rounds of warm-up complete)
         op.step()
+        torch.cuda.synchronize()
     ev = []
     for _ in range(steps):
         op.step(ev)
@@ -343,8 +355,11 @@ def regime_timing(lib, device, B, radius, stream, regime, steps, headline_mpix):
     mpix = B * H * W / ((fwd + bwd) * FRAMES * 1e-3) / 1e6
     del frames, op
     torch.cuda.empty_cache()
-    return {"Mpix_s": round(mpix, 1), "fwd_kernel_ms": round(fwd, 4), "bwd_kernel_ms": round(bwd, 4),
-            "vs_headline": round(mpix / headline_mpix, 3)}
+    res = {"Mpix_s": round(mpix, 1), "fwd_kernel_ms": round(fwd, 4), "bwd_kernel_ms": round(bwd, 4),
+           "vs_headline": round(mpix / headline_mpix, 3)}
+    if radius == _lib.RADIUS_AUTO:
+        res["adaptive_radius"] = adaptive_state(lib, H, W)["radius"]
+    return res
 
 
 def run_train(args, rank, world, device, dist, backend):
@@ -385,7 +400,7 @@ def run_train(args, rank, world, device, dist, backend):
     bwd_gbs = BWD_BYTES * B * H * W / (bwd_ms * 1e-3) / 1e9
     fwd_gbs = FWD_BYTES * B * H * W / (fwd_ms * 1e-3) / 1e9
     traffic, traffic_src = recorded_traffic("synth_bwd_bytes_per_launch", B)
-    if args.radius != -1 or args.sigma != 1.0:  # (recorded at the default radius, sigma 1)
+    if args.radius not in (-1, -2) or args.sigma != 1.0:  # (recorded at the default radius, sigma 1)
         traffic, traffic_src = None, "profiles/pmc_traffic.json holds the default radius at sigma 1 only"
     line = {
         "metric": "synthesized Mpix/s fwd+bwd (4 frames, 1080p)",
@@ -406,7 +421,10 @@ def run_train(args, rank, world, device, dist, backend):
             "batch_per_gpu": B,
             "offset_regime": f"sigma:{args.sigma:g} (i.i.d. N(0, sigma^2) px per pixel and tap)",
             "tile_radius": args.radius,
-            "tile_radius_note": "-1 = the library default (what FunctionSynth callers get)",
+            "tile_radius_note": "-2 = adaptive, the package default (what FunctionSynth callers get): the "
+                                "library picks 8 / 14 / 24 per shape from its forward kernels' reach "
+                                "statistics, no host sync; -1 = fixed 14",
+            "adaptive": adaptive_state(lib, H, W) if args.radius == _lib.RADIUS_AUTO else None,
             "sharding": "batch x timestep, no collective",
             "hbm_frac_of_8TBps_whole_step": round(
                 value * 1e6 * (FWD_BYTES + BWD_BYTES) * FRAMES / world / 1e9 / HBM_PEAK_GBS, 4),
@@ -414,7 +432,9 @@ def run_train(args, rank, world, device, dist, backend):
             "fwd_kernel_GBps": round(fwd_gbs, 1),
         },
         "roofline": {
-            "kernel": "synth_bwd_tapmajor (fused gradWeight/gradOffset_y/gradOffset_x)",
+            "kernel": "synth_bwd_tapmajor (fused gradWeight/gradOffset_y/gradOffset_x)"
+                      + (f", radius {adaptive_state(lib, H, W)['radius']} (adaptive)"
+                         if args.radius == _lib.RADIUS_AUTO else ""),
             "bound": "hbm",
             "achieved": round(bwd_gbs, 1),
             "peak": HBM_PEAK_GBS,
@@ -534,7 +554,8 @@ def run_config2(args, rank, world, device, dist, backend):
             "workload": "config2: synth op forward only, N=16 x 256x448 (Vimeo-90K septuplet), 4 frames "
                         "= 4 launches per step (BASELINE.json configs[1]), k=5 d=1 C=3, fp32",
             "batch_per_gpu": n2, "offset_regime": f"sigma:{args.sigma:g}", "tile_radius": args.radius,
-            "tile_radius_note": "-1 = the library default (what FunctionSynth callers get)",
+            "tile_radius_note": "-2 = adaptive, the package default (what FunctionSynth callers get); -1 = fixed 14",
+            "adaptive": adaptive_state(lib, h2, w2) if args.radius == _lib.RADIUS_AUTO else None,
             "operand_bytes_per_step": FRAMES * fwd_bytes,
             "sharding": "batch, no collective",
         },
@@ -615,7 +636,7 @@ def run_interp7(args, rank, world, device, dist, backend):
     value = TS * H * W / (ms * 1e-3) / 1e6
     # recorded for one 1080p sample (tools/prof_run.py --head); this launch holds n samples of Hl rows
     traffic, traffic_src = recorded_traffic("head_fwd_bytes_per_launch", 1)
-    if traffic is not None and args.radius == -1:
+    if traffic is not None and args.radius in (-1, -2):
         traffic = int(traffic * n * Hl / H)
     else:
         traffic = None
@@ -632,6 +653,7 @@ def run_interp7(args, rank, world, device, dist, backend):
             "timesteps_on_rank0": n, "rows_on_rank0": [sh.y0, sh.y1], "busy_ranks": busy,
             "idle_ranks": world - busy,
             "offset_regime": f"sigma:{args.sigma:g}", "tile_radius": args.radius,
+            "adaptive": adaptive_state(lib, Hl, W, head=True) if args.radius == _lib.RADIUS_AUTO else None,
             "sharding": ("sharding.shard_items(1, 7, rank, world): whole timesteps in balanced blocks"
                          if args.interp_shard == "timesteps" else
                          "sharding.shard_interpolation(7, 1080, rank, world): whole timesteps when the "
@@ -660,11 +682,12 @@ def main():
                          "timesteps when N does not divide 7); timesteps = whole timesteps only")
     ap.add_argument("--batch", type=int, default=1, help="samples per GPU (1080p each)")
     ap.add_argument("--sigma", type=float, default=1.0, help="offset std in pixels (headline: 1)")
-    ap.add_argument("--radius", type=int, default=-1,
-                    help="LDS tile radius passed to the library; -1 = the library default")
-    ap.add_argument("--regimes", default="smooth30,sigma:4,smooth30@24,sigma:1@24",
+    ap.add_argument("--radius", type=int, default=_lib.RADIUS_AUTO,
+                    help="LDS tile radius passed to the library; -2 = adaptive (the package default), "
+                         "-1 = the fixed library default (14)")
+    ap.add_argument("--regimes", default="smooth30,sigma:4,pan,sigma:1@14,smooth30@14",
                     help="other offset regimes timed beside the headline at N = 1 ('' = none); "
-                         "'<regime>@<r>' = at tile radius r (24: the shape for large steep offsets)")
+                         "'<regime>@<r>' = at the FIXED tile radius r")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, host cpus)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-head", action="store_true", help="skip the fused-head side measurement")

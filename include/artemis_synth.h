@@ -24,8 +24,9 @@
  *    thread-local description of the last failure on the calling thread.  No exception crosses
  *    the boundary.
  *  - entry points are reentrant: forward is called from the user's thread, backward from PyTorch's
- *    autograd thread.  The only mutable state of the library is one atomic tuning integer
- *    (artemis_synth_set_small_grid_tiles); it never changes results.
+ *    autograd thread.  The mutable state of the library is one atomic tuning integer
+ *    (artemis_synth_set_small_grid_tiles; never changes results) and, only for callers that pass
+ *    ARTEMIS_SYNTH_RADIUS_AUTO, a mutex-guarded table of per-shape radii (see there).
  *  - empty problems (N, H or W equal to 0) are a successful no-op.
  *  - limits: one (H*W) plane and one padded frame plane must each hold fewer than 2^31
  *    elements; N <= 65535; total element counts are 64-bit (the reference's `const int n`
@@ -59,6 +60,29 @@ extern "C" {
  * always gather directly. */
 #define ARTEMIS_SYNTH_RADIUS_DEFAULT (-1)
 #define ARTEMIS_SYNTH_RADIUS_NONE 0
+/* ARTEMIS_SYNTH_RADIUS_AUTO: the library moves between the radii 8, 14 and 24 by itself, per (device,
+ * H, W, per-frame op | fused head), from what the forward kernels of that shape saw on their earlier
+ * launches: over a sample of the pixels they count the taps displaced beyond 8 and beyond 14 whole
+ * pixels from their window's centre; every few launches a one-wave kernel behind the launch publishes
+ * the counts to pinned host memory, and the next AUTO call -- forward, backward or head -- reads
+ * them with plain host loads and picks the smallest radius that leaves fewer than 5e-5 (8) / 1.5e-4
+ * (14) of the taps to the global fix-up (a factor-two margin before going back down).  No host
+ * synchronisation, no extra pass over the offsets.  A new shape starts at the default (14) and
+ * follows its offsets with a lag of the launches in flight.  Results are those of the chosen fixed
+ * radius: correct for any offsets, equal between radii up to fp32 summation order -- pass a fixed
+ * radius where run-to-run bit equality of the forward matters.  This is the library's one piece of
+ * mutable state beside the small-grid knob (a mutex-guarded table of 16 shapes per device); its one
+ * allocation -- 512 bytes of pinned host memory per device -- happens on the first AUTO FORWARD call
+ * on that device (make that call outside stream capture); backward calls only look the radius up.
+ * Shapes without LDS kernels (k != 5, d != 1, C != 3) treat AUTO as DEFAULT. */
+#define ARTEMIS_SYNTH_RADIUS_AUTO (-2)
+/* ARTEMIS_SYNTH_RADIUS_SMALL: radius 8 in the LEAN shape -- the 128 x 16 tile served by one window that is
+ * staged once around the displacement at its middle: no per-64-column centres, no vote, no further
+ * windows.  For offsets known to stay within 8 pixels of a tile's common displacement (random
+ * initialisation, small or uniform motion); anything else is still correct, through the per-pixel
+ * global fix-up, only slow.  It is what AUTO runs once its statistics show practically no tap
+ * beyond 8 pixels.  grad_input runs its radius-8 kernel. */
+#define ARTEMIS_SYNTH_RADIUS_SMALL (-3)
 
 /* grad_input accumulation mode of artemis_synth_backward */
 #define ARTEMIS_SYNTH_GIN_ATOMIC 0        /* fp32 atomics across tiles; last-bit run-to-run noise */
@@ -213,7 +237,17 @@ int artemis_synth_head_backward(const void *const *frames, int T, const float *w
 int artemis_synth_offset_radius(const float *offset_y, const float *offset_x, size_t count,
                                 int *out_radius, void *stream);
 
-/* Process-wide tuning knob (the only mutable state of the library, one atomic integer): problems
+/* What ARTEMIS_SYNTH_RADIUS_AUTO currently holds for shape (H, W) of the per-frame op (head = 0) or
+ * the fused head (head = 1) on the current device: the radius the next call would run, the
+ * fractions of sampled taps beyond 8 / beyond 14 pixels in the last published window, and the number
+ * of AUTO forward launches seen (0 and the default radius for a shape not seen yet).  Any pointer may
+ * be NULL.  Host-only, no synchronisation.  artemis_synth_auto_reset forgets every shape of the
+ * current device.  No reference counterpart. */
+int artemis_synth_auto_query(int H, int W, int head, int *radius, double *frac8, double *frac14,
+                             unsigned long long *forward_calls);
+void artemis_synth_auto_reset(void);
+
+/* Process-wide tuning knob (one atomic integer): problems
  * with fewer than `tiles` workgroup tiles of 64 x 32 pixels (N * ceil(W/64) * ceil(H/32)) run with
  * 64 x 8 tiles so that small grids (the 64^2 / 128^2 heads of a small-batch training step) still
  * spread over the CUs (the forward switches at a quarter of that count).  Default 768.  0 = never, a huge value = always; results are bit-identical

@@ -14,6 +14,26 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "adaptive: runs with the package's default (adaptive) tile radius")
+
+
+@pytest.fixture(autouse=True)
+def fixed_default_tile_radius(request):
+    """Tests run at the FIXED library default radius unless marked `adaptive`: the package's default
+    (options.tile_radius = adaptive) picks 8 / 14 / 24 from the calls made before, and many tests
+    assert bit equality between separate launches (strips vs whole frames, batches vs samples, fused vs
+    composed), which only holds for one radius.  tests/test_adaptive_radius.py covers the default."""
+    if "adaptive" in request.keywords:
+        yield
+        return
+    import artemis_amd
+    from artemis_amd import _lib
+    old = artemis_amd.options.tile_radius
+    artemis_amd.options.tile_radius = _lib.RADIUS_DEFAULT
+    try:
+        yield
+    finally:
+        artemis_amd.options.tile_radius = old
 
 
 def golden_names():

@@ -69,8 +69,10 @@ def _big_tiles_only(lib):
     return cm()
 
 
-@pytest.mark.parametrize("sigma", [1.0, 0.045])
-def test_config1_op_forward_batch16_vimeo_shape(dev, fast_oracle, sigma):
+@pytest.mark.parametrize("sigma,radius", [(1.0, -1), (0.045, -1), (1.0, -3)])
+def test_config1_op_forward_batch16_vimeo_shape(dev, fast_oracle, sigma, radius):
+    """radius -1: the fixed default (two windows per tile); -3: the lean shape the adaptive default settles
+    on for offsets like these."""
     import artemis_amd
     from artemis_amd import _lib
     lib = _lib.load()
@@ -85,18 +87,19 @@ def test_config1_op_forward_batch16_vimeo_shape(dev, fast_oracle, sigma):
         w = torch.softmax(torch.randn(N, 25, H, W, device=dev, generator=g), 1)
         oy = torch.randn(N, 25, H, W, device=dev, generator=g) * sigma
         ox = torch.randn(N, 25, H, W, device=dev, generator=g) * sigma
-        out = artemis_amd.synth(inp, w, oy, ox, 1)      # ONE launch, default radius
-        torch.cuda.synchronize()
-        assert out.shape == (N, 3, H, W)
-        with _big_tiles_only(lib):
-            for n in range(N):
-                one = artemis_amd.synth(inp[n:n + 1].contiguous(), w[n:n + 1].contiguous(),
-                                        oy[n:n + 1].contiguous(), ox[n:n + 1].contiguous(), 1)
-                assert torch.equal(out[n:n + 1], one), f"frame {f} sample {n}"
+        with artemis_amd.synth_options(tile_radius=radius):
+            out = artemis_amd.synth(inp, w, oy, ox, 1)      # ONE launch
+            torch.cuda.synchronize()
+            assert out.shape == (N, 3, H, W)
+            with _big_tiles_only(lib):
+                for n in range(N):
+                    one = artemis_amd.synth(inp[n:n + 1].contiguous(), w[n:n + 1].contiguous(),
+                                            oy[n:n + 1].contiguous(), ox[n:n + 1].contiguous(), 1)
+                    assert torch.equal(out[n:n + 1], one), f"frame {f} sample {n}"
         for n in (0, 15):
             ref = fast_oracle.forward(np_(inp[n:n + 1]), np_(w[n:n + 1]), np_(oy[n:n + 1]),
                                       np_(ox[n:n + 1]), 1)
-            parity_close(out[n:n + 1], ref, FWD_RTOL, f"config1 op output N16 256x448 sigma {sigma}")
+            parity_close(out[n:n + 1], ref, FWD_RTOL, f"config1 op output N16 256x448 sigma {sigma} R{radius}")
 
 
 def test_config1_head_forward_batch16_vimeo_shape(dev, fast_oracle):
@@ -284,7 +287,7 @@ def test_config4_4k_bf16_strip_against_oracle(dev, fast_oracle, strip):
 
 # ------------------------------------------------------------------ the bench's other offset regimes
 @pytest.mark.parametrize("regime,radius", [("smooth30", -1), ("sigma:4", -1), ("pan", -1), ("smooth30", 24),
-                                           ("sigma:8", 24)])
+                                           ("sigma:8", 24), ("sigma:1", -3), ("pan", -3), ("sigma:4", -3)])
 def test_bench_regimes_at_1080p_against_oracle(dev, fast_oracle, regime, radius):
     """The offset regimes bench.py times beside the headline (config.other_offset_regimes), one
     1080p frame each at the default radius (and the steep / scattered ones at radius 24), forward and

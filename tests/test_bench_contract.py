@@ -55,7 +55,7 @@ def check_line(d, n_gpus):
 def test_single_gpu_line_with_cpu_baseline():
     d = run_bench(QUICK)
     check_line(d, 1)
-    assert d["scaling"] == "weak" and d["config"]["tile_radius"] == -1      # the library default
+    assert d["scaling"] == "weak" and d["config"]["tile_radius"] == -2      # the package default: adaptive
     # value = pixels of the whole job / time of a step
     assert abs(d["value"] - 1080 * 1920 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-3
     c = d["cpu_baseline"]

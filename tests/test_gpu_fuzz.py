@@ -41,7 +41,7 @@ def test_random_case_against_oracle(dev, oracle, case):
     H = int(rng.choice([1, 2, 7, 31, 32, 33, 63, 64, 65, 90]))
     W = int(rng.choice([1, 3, 63, 64, 65, 127, 128, 129, 200]))
     regime = REGIMES[int(rng.integers(len(REGIMES)))]
-    radius = int(rng.choice([-1, 0, 2, 4, 8, 16]))
+    radius = int(rng.choice([-1, 0, 2, 4, 8, 14, 24, -2, -3]))      # (-2: adaptive, whatever it holds)
     det = bool(rng.integers(2))
     weights = "softmax" if rng.random() < 0.5 else "raw"
     inp, w, oy, ox, gout = make_operands(N, C, H, W, k, d, regime, seed=case, weights=weights)
@@ -140,7 +140,7 @@ def test_random_motion_fields_against_oracle(dev, oracle, case):
     N = int(rng.integers(1, 3))
     H = int(rng.choice([16, 33, 48, 70, 100]))
     W = int(rng.choice([64, 100, 128, 150, 257, 300]))
-    radius = int(rng.choice([-1, -1, 2, 4, 8, 24]))
+    radius = int(rng.choice([-1, -2, -3, 2, 4, 8, 14, 24]))
     big_tiles = bool(rng.integers(2))
     old = lib.artemis_synth_set_small_grid_tiles(0 if big_tiles else 1 << 40)
     tag = f"case {case} N{N} {H}x{W} R{radius} big{big_tiles}"

@@ -48,7 +48,7 @@ def run_hip(dev, inp, w, oy, ox, gout, d, radius=-1, deterministic=False, need=(
     return out.detach().cpu().numpy(), [None if x.grad is None else x.grad.cpu().numpy() for x in t]
 
 
-@pytest.mark.parametrize("radius", [-1, 0, 2, 4, 8, 16])
+@pytest.mark.parametrize("radius", [-1, 0, 2, 4, 8, 14, 24])      # default, direct, every built radius
 @pytest.mark.parametrize("name", golden_names())
 def test_golden(dev, name, radius):
     g = load_golden(name)

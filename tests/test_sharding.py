@@ -100,6 +100,51 @@ def test_interpolation_row_strips_reproduce_the_whole_frame_on_gpu(world):
     assert torch.equal(torch.cat(parts, 2), full)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 8])
+def test_interpolation_row_strips_on_a_steep_flow_agree_to_rounding(world):
+    """The documented other half: on large steep motion (the
+    bench's smooth30 field) windows are re-centred and staged again per TILE, tile origins are
+    relative to the strip, so the ranks' strips equal the single launch to the forward tolerance,
+    not bit for bit."""
+    import ctypes
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from artemis_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(6)
+    TS, T, Hh, Ww = 2, 4, 400, 640
+    frames = [torch.rand(1, 3, Hh, Ww, device=dev, generator=g).expand(TS, 3, Hh, Ww).contiguous() for _ in range(T)]
+    w = torch.softmax(torch.randn(TS, T, 25, Hh, Ww, device=dev, generator=g), 2)
+    ab = [bench.make_offsets("smooth30", (TS, 25, Hh, Ww), dev, g) for _ in range(T)]
+    a = torch.stack([p[0] for p in ab], 1).contiguous()
+    b = torch.stack([p[1] for p in ab], 1).contiguous()
+    occ = torch.softmax(torch.randn(TS, T, Hh, Ww, device=dev, generator=g), 1)
+    ptrs = (ctypes.c_void_p * T)(*[f.data_ptr() for f in frames])
+    st = torch.cuda.current_stream().cuda_stream
+
+    def head(wt, at, bt, ot, n, rows, y0):
+        out = torch.empty(n, 3, rows, Ww, device=dev)
+        _lib.check(lib.artemis_synth_head_forward(ptrs, T, wt.data_ptr(), at.data_ptr(), bt.data_ptr(), ot.data_ptr(),
+                                                  out.data_ptr(), n, rows, Ww, Hh, Ww, y0 - 2, -2, 0, -1, st), "head")
+        return out
+
+    full = head(w, a, b, occ, TS, Hh, 0)
+    parts = []
+    for r in range(world):
+        sh = sharding.shard_interpolation(7, Hh, r, world)                # (the row split of 7 timesteps)
+        sl = slice(sh.y0, sh.y1)
+        parts.append(head(w[:, :, :, sl].contiguous(), a[:, :, :, sl].contiguous(), b[:, :, :, sl].contiguous(),
+                          occ[:, :, sl].contiguous(), TS, sh.y1 - sh.y0, sh.y0))
+    torch.cuda.synchronize()
+    got = torch.cat(parts, 2)
+    assert got.shape == full.shape
+    assert float((got - full).abs().max()) <= 1e-5 * float(full.abs().max())
+
+
 def test_row_strips_cover_frame():
     strips = sharding.row_strips(2160, 8, halo=9)
     assert strips[0][0] == 0 and strips[-1][1] == 2160
