@@ -63,7 +63,7 @@ void launch_fwd_tiled(const FT *in, const float *w, const float *oy, const float
 template <int R, class FT>
 void launch_bwd_tiled(const FT *in, const float *w, const float *oy, const float *ox,
                       const float *gout, float *gw, float *goy, float *gox, const Geom &g, bool lean,
-                      hipStream_t st);
+                      unsigned *maxima, hipStream_t st);
 template <int R, class FT>
 void launch_head_fwd(const float *w, const float *oy, const float *ox, float *out, const Geom &g,
                      const HeadArgs &ha, bool lean, unsigned long long *reach_stats, hipStream_t st);
@@ -1192,6 +1192,113 @@ __device__ __forceinline__ void load_tap_col(TapCol<ROWS> &t, const float *__res
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// LDS-DMA operand ring (DMA kernels).  The (w, alpha, beta) rows of the NEXT tap are fetched with
+// global_load_lds_dwordx4 -- 16 bytes per lane straight into LDS, no VGPR destination, nt cache
+// policy -- instead of one dword per lane into registers: per tap and plane ONE wave instruction
+// moves four of the wave's rows x 256 B (lane l: row l / 16, 16-byte chunk l % 16) into a 1 KB slot
+// of the wave's own ring, and the lanes read their pixels back with ds_read_b32.  Measured on the
+// stream-only stand-in of the forward (tools/exp/exp_glds.hip, profiles/r3_glds_standin.log): 90.6 us
+// for the 75 planes of a 1080p frame against 103.8 us for the dword loads (one tap ahead both; with
+// the default cache policy, or two / three taps ahead, the DMA form is SLOWER: 105-122 us).
+// A wave reads only what it fetched itself, so a counted vmcnt orders the reads: no barrier.
+// Needs W % 4 == 0 and 16-byte aligned plane pointers (the launcher checks), ROWS % 4 == 0.
+// OFF by default (SYNTH_DMA): inside the real forward the ring LOSES -- lean shape, 1080p, sigma 1,
+// same-process A/B (profiles/r3_dma_product_ab.log): per-frame forward 128-130 us against 110-112 us,
+// fused head forward 430-439 against 419-430, in both schedules tried (request tap t + 1, then wait
+// for tap t at the top of the tap; or one DMA in flight, moved to registers behind the tap's last
+// row) -- with parity green.  The stand-in has the LDS to itself; the real kernel's 16 ds_read_b128
+// per tap and row already keep it busy, and the DMA's LDS writes queue behind them.
+// ------------------------------------------------------------------------------------------
+#ifndef SYNTH_DMA
+#define SYNTH_DMA 0
+#endif
+typedef __attribute__((address_space(3))) float lds_float;
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int ROWS>
+struct DmaRing {
+    static constexpr int K = ROWS / 4;           // wave instructions per plane and tap
+    static constexpr int kSlot = 3 * ROWS * 64;  // floats per tap: 3 planes x ROWS rows x 64 pixels
+    static constexpr int kPerTap = 3 * K;        // wave instructions per tap
+    lds_float *base;                             // this wave's two slots
+    size_t src[K];                               // this lane's source offset inside a plane, per instruction
+    int xl;                                      // this lane's pixel inside a row
+};
+
+// rowy: the wave's pixel rows (clamped to the image); x0: its first column
+template <int ROWS>
+__device__ __forceinline__ DmaRing<ROWS> dma_ring(float *ring_all, int wv, const int (&rowy)[ROWS],
+                                                  int x0, const Geom &g)
+{
+    DmaRing<ROWS> r;
+    r.base = (lds_float *)ring_all + wv * (2 * DmaRing<ROWS>::kSlot);
+    const int l = threadIdx.x & 63;
+    r.xl = min(l, g.W - 1 - x0);  // lanes past the right edge act as the last column
+    const int col = min(x0 + 4 * (l & 15), g.W - 4);
+#pragma unroll
+    for (int k = 0; k < DmaRing<ROWS>::K; ++k) {
+        int y = rowy[4 * k];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) y = (l >> 4) == q ? rowy[4 * k + q] : y;
+        r.src[k] = (size_t)y * g.W + col;
+    }
+    return r;
+}
+
+// One LDS-DMA instruction: 16 bytes per lane from `gsrc` (per lane) to LDS byte address `lds_byte`
+// (wave-uniform) + lane * 16, nt.  Inline asm, not __builtin_amdgcn_global_load_lds: with the builtin
+// hipcc puts an s_waitcnt vmcnt(0) in front of the first LDS read that follows (it cannot tell the
+// window reads from the ring), which waits for the tap just requested and undoes the prefetch.  The
+// asm form is absent from the compiler's vmcnt bookkeeping -- its own waits only get stricter -- and
+// the reads are ordered by wait_vmcnt above.  M0 (the LDS base of the DMA) is saved and restored
+// inside the statement.
+__device__ __forceinline__ void glds16_nt(const float *gsrc, unsigned lds_byte)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_byte)
+                 : "memory");
+}
+
+template <int ROWS>
+__device__ __forceinline__ void dma_issue(const DmaRing<ROWS> &r, const float *__restrict__ wb,
+                                          const float *__restrict__ ab, const float *__restrict__ bb,
+                                          size_t plane, int tap, int slot)
+{
+    // (an address_space(3) pointer's value is the byte offset inside the workgroup's LDS)
+    const unsigned d = (unsigned)__builtin_amdgcn_readfirstlane(
+        (int)(unsigned)(size_t)(r.base + slot * DmaRing<ROWS>::kSlot));
+#pragma unroll
+    for (int k = 0; k < DmaRing<ROWS>::K; ++k) {
+        const size_t o = (size_t)tap * plane + r.src[k];
+        glds16_nt(wb + o, d + k * 1024);
+        glds16_nt(ab + o, d + ROWS * 256 + k * 1024);
+        glds16_nt(bb + o, d + 2 * ROWS * 256 + k * 1024);
+    }
+}
+
+template <int ROWS>
+__device__ __forceinline__ void dma_read(const DmaRing<ROWS> &r, TapCol<ROWS> &t, int slot)
+{
+    const lds_float *s = r.base + slot * DmaRing<ROWS>::kSlot + r.xl;
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+        t.w[j] = s[j * 64];
+        t.a[j] = s[ROWS * 64 + j * 64];
+        t.b[j] = s[2 * ROWS * 64 + j * 64];
+    }
+}
+
 // Stage the clamped frame window.  Texels are fetched in batches with all of a batch's loads issued
 // before the first LDS write: left to itself hipcc waits vmcnt(0) after every texel, which
 // serialises ~14 L2 round trips (~10 us) at the head of every workgroup.  The batch size balances
@@ -1295,8 +1402,9 @@ static __device__ unsigned long long *g_tile_log;
 
 // PASSES: how many windows a tile may stage per frame (kMaxPasses; 1 = the first window only: no vote,
 // no further passes -- the lean shape for offsets known to stay within the radius, synth_tiles.hip)
+// DMA: the operand planes come through the LDS-DMA ring above (lean shape only: PASSES == 1).
 template <int R, int WAVES, int ROWS, int OCC, bool HEAD, class FT, int WX = 1, int NWIN = 1,
-          int PASSES = kMaxPasses>
+          int PASSES = kMaxPasses, bool DMA = false>
 __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
     const FT *__restrict__ in, const float *__restrict__ w, const float *__restrict__ oy,
     const float *__restrict__ ox, float *__restrict__ out, Geom g, HeadArgs ha,
@@ -1312,6 +1420,9 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
     static_assert(WX % NWIN == 0, "wave columns must split evenly over the windows");
     __shared__ f32x4 tile_all[NWIN * LH * LW];
     __shared__ float vote_slot[WAVES * kVoteSlots];
+    static_assert(!DMA || (PASSES == 1 && ROWS % 4 == 0), "the DMA ring serves the single-pass shapes");
+    constexpr int DR = ROWS % 4 == 0 ? ROWS : 4;  // (the ring's type must exist for every ROWS)
+    __shared__ __attribute__((aligned(16))) float dma_all[DMA ? WAVES * 2 * DmaRing<DR>::kSlot : 4];
 #ifdef SYNTH_DEV_TILE_CLOCK
     const unsigned long long dbg_t0 = wall_clock64();
     unsigned long long dbg_t1 = 0, dbg_t2 = 0, dbg_a = 0, dbg_b = 0, dbg_c = 0;
@@ -1356,6 +1467,8 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
         roff[j] = (size_t)rowy[j] * g.W;
         rowbase[j] = ((rowy[j] - ty0 + R) * LW + px + R) * 16;
     }
+    DmaRing<DR> ring;
+    if constexpr (DMA) ring = dma_ring<ROWS>(dma_all, wv, rowy, wx0, g);
     float res0[ROWS], res1[ROWS], res2[ROWS];  // HEAD: the running sum over frames
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) res0[j] = res1[j] = res2[j] = 0.f;
@@ -1385,7 +1498,8 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
         TapCol<ROWS> cur;
         float occv[ROWS];
         if (active) {
-            load_tap_col<ROWS>(cur, wb, ab, bb, pl, 0, rf, (unsigned)x);
+            if constexpr (DMA) dma_issue<ROWS>(ring, wb, ab, bb, pl, 0, 0);
+            else load_tap_col<ROWS>(cur, wb, ab, bb, pl, 0, rf, (unsigned)x);
             if constexpr (HEAD) {
                 const float *op = ha.occ + ((size_t)n * T + f) * pl;
 #pragma unroll
@@ -1407,14 +1521,32 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
         auto run_taps = [&](auto first_tag, const Centre ctr) {
             constexpr bool FIRST = decltype(first_tag)::value != 0;
             const int cbase = (((int)ctr.y) * LW + (int)ctr.x) * 16;  // the window's shift
+            if constexpr (DMA) {  // tap 0 (requested before the fill) to registers, tap 1 requested
+                wait_vmcnt<0>();
+                dma_read<ROWS>(ring, cur, 0);
+                dma_issue<ROWS>(ring, wb, ab, bb, pl, 1, 1);
+            }
             static_for<0, 25>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
                 constexpr int r = t / 5, s = t % 5;
                 TapCol<ROWS> nxt;
-                if (t < 24) load_tap_col<ROWS>(nxt, wb, ab, bb, pl, t + 1, rf, (unsigned)x);
+                if constexpr (!DMA) {
+                    if (t < 24) load_tap_col<ROWS>(nxt, wb, ab, bb, pl, t + 1, rf, (unsigned)x);
+                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < ROWS; ++j) {
+                    if constexpr (DMA) {
+                        // Before the tap's last row: tap t + 1 (requested a tap ago) has landed -- it is
+                        // the only DMA in flight, which is what the DRAM wants -- so its values move
+                        // from the ring to registers behind this row's arithmetic, and tap t + 2 is
+                        // requested into the slot tap t came from.
+                        if (j == ROWS - 1 && t < 24) {
+                            wait_vmcnt<0>();
+                            dma_read<ROWS>(ring, nxt, (t + 1) & 1);
+                            if (t < 23) dma_issue<ROWS>(ring, wb, ab, bb, pl, t + 2, t & 1);
+                        }
+                    }
                     const float wv = cur.w[j], a = cur.a[j], b = cur.b[j];
                     const int ia = (int)a, ib = (int)b;
                     const float fa = a - (float)ia, fb = b - (float)ib;
@@ -1624,7 +1756,7 @@ template <int R, int WAVES, int ROWS, int OCC, bool ALL, bool HEAD, class FT, in
 __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
     const FT *__restrict__ in, const float *__restrict__ w, const float *__restrict__ oy,
     const float *__restrict__ ox, const float *__restrict__ gout, float *__restrict__ gw,
-    float *__restrict__ goy, float *__restrict__ gox, Geom g, HeadArgs ha)
+    float *__restrict__ goy, float *__restrict__ gox, Geom g, HeadArgs ha, unsigned *__restrict__ maxima)
 {
     // WX waves side by side: the tile is 64 * WX pixels wide and (WAVES / WX) * ROWS rows high
     constexpr int TW = 64 * WX, WY = WAVES / WX, TH = WY * ROWS;
@@ -1671,6 +1803,9 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
     }
     const float *gb_ = gout + (size_t)n * 3 * plane;
     float d[ROWS][3];
+    // max |weight| and max |gradOutput| over this lane's pixels, for the caller's gradInput pass
+    // (its fixed-point scale; saves that pass a 53 us sweep over the weights): maxima[0], maxima[1]
+    unsigned mx_w = 0u, mx_g = 0u;
 
     const int T = HEAD ? ha.T : 1;
     bool tile_free = true;  // no wave will read the staged windows again before the next barrier
@@ -1741,6 +1876,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
                     bool near = reach <= (float)R;
                     if constexpr (FIRST) {
                         fmask[j] |= near ? 0u : 1u << t;
+                        if constexpr (!HEAD) mx_w = max(mx_w, absbits(wv));
                     } else {
                         near = near && ((fmask[j] >> t) & 1u);
                         fmask[j] &= near ? ~(1u << t) : ~0u;
@@ -1849,6 +1985,8 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
                             d[j][0] = ld_stream(gb_ + rf[j] + (unsigned)x);
                             d[j][1] = ld_stream(gb_ + pl + rf[j] + (unsigned)x);
                             d[j][2] = ld_stream(gb_ + 2 * pl + rf[j] + (unsigned)x);
+                            if constexpr (!HEAD)
+                                mx_g = max(mx_g, max(absbits(d[j][0]), max(absbits(d[j][1]), absbits(d[j][2]))));
                         }
                     }
                     run_taps(IntTag<1>{}, ctr);
@@ -1916,6 +2054,20 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
             if constexpr (HEAD) {
                 if (ha.gocc)
                     st_stream(ha.gocc + ((size_t)n * T + f) * pl + rf[j] + (unsigned)x, gocc[j]);
+            }
+        }
+    }
+    if constexpr (!HEAD) {
+        if (maxima && active) {  // wave-uniform
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                mx_w = max(mx_w, (unsigned)__shfl_xor((int)mx_w, o));
+                mx_g = max(mx_g, (unsigned)__shfl_xor((int)mx_g, o));
+            }
+            // only when it can raise the running maximum (same-address atomics serialise in L2)
+            if (threadIdx.x == 0) {
+                if (mx_w > __atomic_load_n(maxima, __ATOMIC_RELAXED)) atomicMax(maxima, mx_w);
+                if (mx_g > __atomic_load_n(maxima + 1, __ATOMIC_RELAXED)) atomicMax(maxima + 1, mx_g);
             }
         }
     }

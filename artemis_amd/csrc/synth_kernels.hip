@@ -201,25 +201,25 @@ void dispatch_fwd_tiled(int R, const void *input, const float *weight, const flo
 template <class FT>
 void dispatch_bwd_tiled(int R, const void *input, const float *weight, const float *offset_y,
                                const float *offset_x, const float *grad_output, float *gw, float *goy,
-                               float *gox, const Geom &g, bool lean, hipStream_t st)
+                               float *gox, const Geom &g, bool lean, unsigned *maxima, hipStream_t st)
 {
     const FT *in = (const FT *)input;
     switch (R) {
     case 2:
         if constexpr (kSmallRadiiBuilt<FT>) {
-            launch_bwd_tiled<2, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, lean, st);
+            launch_bwd_tiled<2, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, lean, maxima, st);
             break;
         }
         [[fallthrough]];
     case 4:
         if constexpr (kSmallRadiiBuilt<FT>) {
-            launch_bwd_tiled<4, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, lean, st);
+            launch_bwd_tiled<4, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, lean, maxima, st);
             break;
         }
         [[fallthrough]];
-    case 8: launch_bwd_tiled<8, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, lean, st); break;
-    case 24: launch_bwd_tiled<24, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, lean, st); break;
-    default: launch_bwd_tiled<14, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, lean, st); break;
+    case 8: launch_bwd_tiled<8, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, lean, maxima, st); break;
+    case 24: launch_bwd_tiled<24, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, lean, maxima, st); break;
+    default: launch_bwd_tiled<14, FT>(in, weight, offset_y, offset_x, grad_output, gw, goy, gox, g, lean, maxima, st); break;
     }
 }
 
@@ -586,16 +586,41 @@ static int run_backward(const Geom &g, int rc, const void *input_any, const floa
     // AUTO: the radius the forward launches of this shape have settled on (no statistics here)
     if (tile_radius == ARTEMIS_SYNTH_RADIUS_AUTO && tiled_ok(g)) tile_radius = auto_begin(g, 0, false).radius;
 
+    // gradInput's set-up comes first: its workspace header receives max |weight| and max |gradOutput|
+    // (the fixed-point scale) from the tap-gradient kernel when that runs anyway -- one sweep over the
+    // weights less (53 us at 1080p) -- and from a launch of its own otherwise.
+    const int Rg = (grad_input && tiled_ok(g)) ? gin_radius(tile_radius) : 0;
+    const bool fixed = gin_mode == ARTEMIS_SYNTH_GIN_DETERMINISTIC;
+    const size_t need = grad_input ? ws_bytes_needed(g, gin_mode, Rg) : 0;
+    unsigned char *ws = (unsigned char *)workspace;
+    if (grad_input) {
+        if (need && (!workspace || workspace_bytes < need))
+            return fail(hipErrorInvalidValue,
+                        "artemis_synth_backward: grad_input needs %zu workspace bytes "
+                        "(artemis_synth_backward_workspace_bytes), got %zu", need,
+                        workspace ? workspace_bytes : (size_t)0);
+        if (need && ((uintptr_t)workspace & 15) != 0)
+            return fail(hipErrorInvalidValue, "artemis_synth_backward: workspace not 16-byte aligned");
+        hipError_t e = hipSuccess;
+        if (need) e = hipMemsetAsync(ws, 0, need, st);
+        if (e == hipSuccess && !fixed) e = hipMemsetAsync(grad_input, 0, gin_count * sizeof(float), st);
+        if (e != hipSuccess) return fail((int)e, "hipMemsetAsync: %s", hipGetErrorString(e));
+    }
+    bool have_maxima = false;
+
     if (grad_weight || grad_offset_y || grad_offset_x) {
         const int R = tiled_radius(g, tile_radius, frame_dtype);
         const bool lean = is_lean(tile_radius);
         if (R > 0) {
+            unsigned *maxima = need ? (unsigned *)ws : nullptr;
+            have_maxima = maxima != nullptr;
             if (frame_dtype == ARTEMIS_SYNTH_FRAME_BF16)
                 dispatch_bwd_tiled<asynth::bf16_t>(R, input_any, weight, offset_y, offset_x, grad_output,
-                                                   grad_weight, grad_offset_y, grad_offset_x, g, lean, st);
+                                                   grad_weight, grad_offset_y, grad_offset_x, g, lean, maxima,
+                                                   st);
             else
                 dispatch_bwd_tiled<float>(R, input_any, weight, offset_y, offset_x, grad_output,
-                                          grad_weight, grad_offset_y, grad_offset_x, g, lean, st);
+                                          grad_weight, grad_offset_y, grad_offset_x, g, lean, maxima, st);
         } else {
             if (k == 5 && C == 3)
                 hipLaunchKernelGGL((synth_bwd_direct<3, 5>), pixel_grid(g, 4), dim3(64, 4), 0, st, input,
@@ -611,23 +636,8 @@ static int run_backward(const Geom &g, int rc, const void *input_any, const floa
     }
 
     if (grad_input) {
-        const int Rg = tiled_ok(g) ? gin_radius(tile_radius) : 0;
         const int bits = count_bits_for(g);
-        const bool fixed = gin_mode == ARTEMIS_SYNTH_GIN_DETERMINISTIC;
-        const size_t need = ws_bytes_needed(g, gin_mode, Rg);
-        if (need && (!workspace || workspace_bytes < need))
-            return fail(hipErrorInvalidValue,
-                        "artemis_synth_backward: grad_input needs %zu workspace bytes "
-                        "(artemis_synth_backward_workspace_bytes), got %zu", need,
-                        workspace ? workspace_bytes : (size_t)0);
-        if (need && ((uintptr_t)workspace & 15) != 0)
-            return fail(hipErrorInvalidValue, "artemis_synth_backward: workspace not 16-byte aligned");
-        unsigned char *ws = (unsigned char *)workspace;
-        hipError_t e = hipSuccess;
-        if (need) e = hipMemsetAsync(ws, 0, need, st);
-        if (e == hipSuccess && !fixed) e = hipMemsetAsync(grad_input, 0, gin_count * sizeof(float), st);
-        if (e != hipSuccess) return fail((int)e, "hipMemsetAsync: %s", hipGetErrorString(e));
-        if (need) {  // maxima for the fixed-point scale
+        if (need && !have_maxima) {  // maxima for the fixed-point scale
             const size_t wcount = (size_t)N * k * k * H * W, gcount = (size_t)N * C * H * W;
             // one launch for both maxima; ~16 KB of 16-byte loads per block and pass
             const int vec = (((uintptr_t)weight | (uintptr_t)grad_output) & 15) == 0;

@@ -48,7 +48,7 @@ template <int R>
 struct TileCfg {
     static constexpr int WAVES = SYNTH_WAVES, WX = SYNTH_WX, ROWS = SYNTH_ROWS, OCC = SYNTH_OCC,
                          NWIN = SYNTH_NWIN, PASSES = kMaxPasses;
-    static constexpr bool kSolo = SYNTH_ONE_WG_PER_CU;
+    static constexpr bool kSolo = SYNTH_ONE_WG_PER_CU, DMA = false;
 };
 
 // Small grids: a problem with fewer than small_grid_tiles() (default 768) tiles of 64 x 32 pixels (the 64^2 and 128^2
@@ -72,7 +72,7 @@ struct BwdCfg {
     // second workgroup) to 256 registers and spilled 60-240 of them
     static constexpr int WAVES = SYNTH_BWD_WAVES, WX = SYNTH_WX, ROWS = SYNTH_BWD_ROWS, OCC = 1,
                          NWIN = SYNTH_NWIN, PASSES = kMaxPasses;
-    static constexpr bool kSolo = true;
+    static constexpr bool kSolo = true, DMA = false;
 };
 
 // The LEAN shape (tile_radius ARTEMIS_SYNTH_RADIUS_SMALL; what ARTEMIS_SYNTH_RADIUS_AUTO runs once the
@@ -84,11 +84,12 @@ struct BwdCfg {
 // forward: 466 us with it, 441 without the vote, 392 in round 1), which this shape gives back.
 struct LeanCfg {
     static constexpr int WAVES = 8, WX = 2, ROWS = 4, OCC = 2, NWIN = 1, PASSES = 1;
-    static constexpr bool kSolo = true;
+    // the operand planes through the LDS-DMA ring (synth_device.hpp): window 88 KB + ring 48 KB
+    static constexpr bool kSolo = true, DMA = SYNTH_DMA;
 };
 struct LeanBwdCfg {
     static constexpr int WAVES = 4, WX = 2, ROWS = 8, OCC = 1, NWIN = 1, PASSES = 1;
-    static constexpr bool kSolo = true;
+    static constexpr bool kSolo = true, DMA = false;
 };
 
 // Radius 24 (tile_radius > 14, for callers whose offsets are large): one window of
@@ -101,17 +102,17 @@ struct LeanBwdCfg {
 template <>
 struct TileCfg<24> {
     static constexpr int WAVES = 8, WX = 1, ROWS = 4, OCC = 2, NWIN = 1, PASSES = kMaxPasses;
-    static constexpr bool kSolo = false;
+    static constexpr bool kSolo = false, DMA = false;
 };
 template <>
 struct BwdCfg<24> {
     static constexpr int WAVES = 8, WX = 1, ROWS = 4, OCC = 2, NWIN = 1, PASSES = kMaxPasses;
-    static constexpr bool kSolo = false;
+    static constexpr bool kSolo = false, DMA = false;
 };
 
 struct SmallCfg {
     static constexpr int WAVES = 4, WX = 1, ROWS = 2, OCC = 2, NWIN = 1, PASSES = kMaxPasses;
-    static constexpr bool kSolo = false;
+    static constexpr bool kSolo = false, DMA = false;
 };
 
 // dynamic LDS that keeps a second workgroup off the CU (160 KB per CU) when the config wants that
@@ -126,6 +127,12 @@ unsigned lds_pad()
 // The backward (more work per tile, more sensitive to a ragged last round of workgroups) switches
 // at the knob, the forward at a quarter of it: measured crossovers on 256 CUs are ~770 and ~160
 // tiles (tools/head_sweep.py).
+// the DMA ring moves 16-byte pieces of plane rows: rows and planes must start on 16-byte boundaries
+inline bool dma_ok(const asynth::Geom &g, const float *w, const float *oy, const float *ox)
+{
+    return (g.W & 3) == 0 && (((uintptr_t)w | (uintptr_t)oy | (uintptr_t)ox) & 15) == 0;
+}
+
 template <class T>
 bool small_grid(const asynth::Geom &g, bool backward)
 {
@@ -151,17 +158,17 @@ void fwd_cfg(bool head, const FT *in, const float *w, const float *oy, const flo
     const dim3 grid = cfg_grid<T>(g), block(64, T::WAVES);
     const unsigned pad = lds_pad<R, T>();
     if (head)
-        hipLaunchKernelGGL((synth_fwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true, FT, T::WX, T::NWIN, T::PASSES>), grid, block,
+        hipLaunchKernelGGL((synth_fwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true, FT, T::WX, T::NWIN, T::PASSES, T::DMA>), grid, block,
                            pad, st, in, w, oy, ox, out, g, ha, stats);
     else
-        hipLaunchKernelGGL((synth_fwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false, FT, T::WX, T::NWIN, T::PASSES>), grid, block,
+        hipLaunchKernelGGL((synth_fwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false, FT, T::WX, T::NWIN, T::PASSES, T::DMA>), grid, block,
                            pad, st, in, w, oy, ox, out, g, ha, stats);
 }
 
 template <int R, class T, class FT>
 void bwd_cfg(bool head, const FT *in, const float *w, const float *oy, const float *ox,
              const float *gout, float *gw, float *goy, float *gox, const asynth::Geom &g,
-             const asynth::HeadArgs &ha, hipStream_t st)
+             const asynth::HeadArgs &ha, unsigned *maxima, hipStream_t st)
 {
     const dim3 grid = cfg_grid<T>(g), block(64, T::WAVES);
     const unsigned pad = lds_pad<R, T>();
@@ -169,17 +176,17 @@ void bwd_cfg(bool head, const FT *in, const float *w, const float *oy, const flo
     if (head) {
         if (all)
             hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true, true, FT, T::WX, T::NWIN, T::PASSES>), grid,
-                               block, pad, st, in, w, oy, ox, gout, gw, goy, gox, g, ha);
+                               block, pad, st, in, w, oy, ox, gout, gw, goy, gox, g, ha, maxima);
         else
             hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false, true, FT, T::WX, T::NWIN, T::PASSES>), grid,
-                               block, pad, st, in, w, oy, ox, gout, gw, goy, gox, g, ha);
+                               block, pad, st, in, w, oy, ox, gout, gw, goy, gox, g, ha, maxima);
     } else {
         if (all)
             hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, true, false, FT, T::WX, T::NWIN, T::PASSES>), grid,
-                               block, pad, st, in, w, oy, ox, gout, gw, goy, gox, g, ha);
+                               block, pad, st, in, w, oy, ox, gout, gw, goy, gox, g, ha, maxima);
         else
             hipLaunchKernelGGL((synth_bwd_tapmajor<R, T::WAVES, T::ROWS, T::OCC, false, false, FT, T::WX, T::NWIN, T::PASSES>), grid,
-                               block, pad, st, in, w, oy, ox, gout, gw, goy, gox, g, ha);
+                               block, pad, st, in, w, oy, ox, gout, gw, goy, gox, g, ha, maxima);
     }
 }
 
@@ -196,7 +203,7 @@ void launch_fwd_tiled(const FT *in, const float *w, const float *oy, const float
         return;
     }
     if constexpr (R == 8) {  // (the lean shape is built for radius 8 only)
-        if (lean) {
+        if (lean && (!LeanCfg::DMA || dma_ok(g, w, oy, ox))) {
             fwd_cfg<R, LeanCfg, FT>(false, in, w, oy, ox, out, g, HeadArgs{}, stats, st);
             return;
         }
@@ -207,19 +214,19 @@ void launch_fwd_tiled(const FT *in, const float *w, const float *oy, const float
 template <int R, class FT>
 void launch_bwd_tiled(const FT *in, const float *w, const float *oy, const float *ox,
                       const float *gout, float *gw, float *goy, float *gox, const Geom &g, bool lean,
-                      hipStream_t st)
+                      unsigned *maxima, hipStream_t st)
 {
     if (small_grid<TileCfg<R>>(g, true)) {
-        bwd_cfg<R, SmallCfg, FT>(false, in, w, oy, ox, gout, gw, goy, gox, g, HeadArgs{}, st);
+        bwd_cfg<R, SmallCfg, FT>(false, in, w, oy, ox, gout, gw, goy, gox, g, HeadArgs{}, maxima, st);
         return;
     }
     if constexpr (R == 8) {
         if (lean) {
-            bwd_cfg<R, LeanBwdCfg, FT>(false, in, w, oy, ox, gout, gw, goy, gox, g, HeadArgs{}, st);
+            bwd_cfg<R, LeanBwdCfg, FT>(false, in, w, oy, ox, gout, gw, goy, gox, g, HeadArgs{}, maxima, st);
             return;
         }
     }
-    bwd_cfg<R, BwdCfg<R>, FT>(false, in, w, oy, ox, gout, gw, goy, gox, g, HeadArgs{}, st);
+    bwd_cfg<R, BwdCfg<R>, FT>(false, in, w, oy, ox, gout, gw, goy, gox, g, HeadArgs{}, maxima, st);
 }
 
 template <int R, class FT>
@@ -231,7 +238,7 @@ void launch_head_fwd(const float *w, const float *oy, const float *ox, float *ou
         return;
     }
     if constexpr (R == 8) {
-        if (lean) {
+        if (lean && (!LeanCfg::DMA || dma_ok(g, w, oy, ox))) {
             fwd_cfg<R, LeanCfg, FT>(true, (const FT *)nullptr, w, oy, ox, out, g, ha, stats, st);
             return;
         }
@@ -244,16 +251,16 @@ void launch_head_bwd(const float *w, const float *oy, const float *ox, const flo
                      float *goy, float *gox, const Geom &g, const HeadArgs &ha, bool lean, hipStream_t st)
 {
     if (small_grid<TileCfg<R>>(g, true)) {
-        bwd_cfg<R, SmallCfg, FT>(true, (const FT *)nullptr, w, oy, ox, gout, gw, goy, gox, g, ha, st);
+        bwd_cfg<R, SmallCfg, FT>(true, (const FT *)nullptr, w, oy, ox, gout, gw, goy, gox, g, ha, nullptr, st);
         return;
     }
     if constexpr (R == 8) {
         if (lean) {
-            bwd_cfg<R, LeanBwdCfg, FT>(true, (const FT *)nullptr, w, oy, ox, gout, gw, goy, gox, g, ha, st);
+            bwd_cfg<R, LeanBwdCfg, FT>(true, (const FT *)nullptr, w, oy, ox, gout, gw, goy, gox, g, ha, nullptr, st);
             return;
         }
     }
-    bwd_cfg<R, BwdCfg<R>, FT>(true, (const FT *)nullptr, w, oy, ox, gout, gw, goy, gox, g, ha, st);
+    bwd_cfg<R, BwdCfg<R>, FT>(true, (const FT *)nullptr, w, oy, ox, gout, gw, goy, gox, g, ha, nullptr, st);
 }
 
 // gradInput tiles: 64 x 16 pixels, 64-bit accumulators (3 x 29 x 77 x 8 B = 53.6 KB at R = 4,
@@ -291,7 +298,7 @@ template void launch_fwd_tiled<SYNTH_TILE_R, frame_t>(const frame_t *, const flo
 #ifndef SYNTH_DEV_ONLY_FWD  // (developer builds: compile just the forward to look at its registers)
 template void launch_bwd_tiled<SYNTH_TILE_R, frame_t>(const frame_t *, const float *, const float *,
                                                       const float *, const float *, float *, float *,
-                                                      float *, const Geom &, bool, hipStream_t);
+                                                      float *, const Geom &, bool, unsigned *, hipStream_t);
 template void launch_head_fwd<SYNTH_TILE_R, frame_t>(const float *, const float *, const float *,
                                                      float *, const Geom &, const HeadArgs &, bool,
                                                      unsigned long long *, hipStream_t);

@@ -210,12 +210,13 @@ def test_offset_radius_helper(dev):
 
 def test_suggest_tile_radius(dev):
     import artemis_amd
-    from artemis_amd import _lib
     oy = torch.randn(1, 25, 16, 64, device=dev)
     ox = torch.randn(1, 25, 16, 64, device=dev)
-    assert artemis_amd.suggest_tile_radius(oy, ox) == _lib.RADIUS_DEFAULT   # within the default window
+    assert artemis_amd.suggest_tile_radius(oy, ox) == 8      # N(0, 1): every whole-pixel offset within 8
+    oy[0, 7, 3, 3] = 8.9
+    assert artemis_amd.suggest_tile_radius(oy, ox) == 8
     oy[0, 7, 3, 3] = 14.9
-    assert artemis_amd.suggest_tile_radius(oy, ox) == _lib.RADIUS_DEFAULT
+    assert artemis_amd.suggest_tile_radius(oy, ox) == 14
     oy[0, 7, 3, 3] = -15.0
     assert artemis_amd.suggest_tile_radius(oy, ox) == 24
     with artemis_amd.synth_options(tile_radius=artemis_amd.suggest_tile_radius(oy, ox)):

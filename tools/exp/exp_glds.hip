@@ -134,6 +134,9 @@ template <int D, int AUX>
 static void launch_glds(dim3 grid, unsigned pad, hipStream_t st, const float *w, const float *oy, const float *ox,
                         float *out, int H, int W)
 {
+    // static ring: 8 waves x (D + 1) slots x 3 KB; pad only up to "a second workgroup does not fit"
+    const unsigned ring = 8u * (D + 1) * 3072u;
+    pad = ring >= pad ? 0u : pad - ring;
     hipLaunchKernelGGL((stream_glds<D, AUX>), grid, dim3(64, 8), pad, st, w, oy, ox, out, H, W);
 }
 

@@ -98,6 +98,14 @@ def main():
                 None, gw.data_ptr(), ga.data_ptr(), gb.data_ptr(), N, 3, H, W, 5, 1, 0, r,
                 None, 0, st), "bwd"), bwd_b)
         if args.gin:
+            # the whole backward in one call (tap gradients + gradInput: the scale's maxima then come
+            # from the tap kernel), per radius; the printed increment over `bwd r=` is gradInput's cost
+            for r in radii:
+                for mode, nm in ((0, "atomic"), (1, "determ")):
+                    variants[f"all {nm} r={r}"] = (lambda r=r, mode=mode: _lib.check(lib.artemis_synth_backward(
+                        inp.data_ptr(), w.data_ptr(), oy.data_ptr(), ox.data_ptr(), gout.data_ptr(),
+                        gin.data_ptr(), gw.data_ptr(), ga.data_ptr(), gb.data_ptr(), N, 3, H, W, 5, 1, mode, r,
+                        ws.data_ptr(), ws_bytes, st), "all"), bwd_b + gin_b)
             for mode, nm in ((0, "gin atomic"), (1, "gin determ")):
                 variants[nm] = (lambda mode=mode: _lib.check(lib.artemis_synth_backward(
                     inp.data_ptr(), w.data_ptr(), oy.data_ptr(), ox.data_ptr(), gout.data_ptr(),
@@ -114,8 +122,12 @@ def main():
         print(f"-- {name}")
         for k, (fn, nbytes) in variants.items():
             med = statistics.median(times[k])
-            print(f"   {k:14s} {med*1e3:9.1f} us  min {min(times[k])*1e3:9.1f} us  "
-                  f"{nbytes/med/1e6:8.1f} GB/s  ({nbytes/med/1e6/8000*100:5.1f}% of 8 TB/s)")
+            extra = ""
+            if k.startswith("all "):
+                base = statistics.median(times["bwd " + k.split()[-1]])
+                extra = f"  gradInput's share {1e3 * (med - base):7.1f} us"
+            print(f"   {k:18s} {med*1e3:9.1f} us  min {min(times[k])*1e3:9.1f} us  "
+                  f"{nbytes/med/1e6:8.1f} GB/s  ({nbytes/med/1e6/8000*100:5.1f}% of 8 TB/s){extra}")
 
 
 if __name__ == "__main__":
