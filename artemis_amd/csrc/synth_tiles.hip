@@ -80,8 +80,9 @@ struct BwdCfg {
 // 128 x 16 tile served by ONE 128-column window staged once -- no per-64-column centres, no vote, no
 // further windows; a stray tap still takes the per-pixel global fix-up, so any offsets are correct.
 // It is round 1's kernel shape: the windows-follow-the-motion machinery costs the i.i.d. small-offset
-// regimes 2-5 % on the per-frame kernels and 15-20 % on the fused head's forward (1080p, sigma 1, head
-// forward: 466 us with it, 441 without the vote, 392 in round 1), which this shape gives back.
+// regimes 1-2 % on the per-frame kernels and 10 % on the fused head's forward (1080p, sigma 1, same
+// process, tools/ab.py: head forward 451-466 us with it at radius 8, 441 without the vote, 419-423 in
+// this shape; per-frame forward / backward 113.5 / 242.8 -> 112.1 / 240.2 us).
 struct LeanCfg {
     static constexpr int WAVES = 8, WX = 2, ROWS = 4, OCC = 2, NWIN = 1, PASSES = 1;
     // the operand planes through the LDS-DMA ring (synth_device.hpp): window 88 KB + ring 48 KB

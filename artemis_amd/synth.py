@@ -111,9 +111,13 @@ def _frame_dtype(t):
 
 def _tile_radius():
     """options.tile_radius as passed to the library: the adaptive choice depends on the calls made
-    before, so callers who asked for reproducible results get the fixed default instead."""
+    before, so callers who asked for reproducible results get the fixed default instead -- and so do
+    calls under HIP graph capture: a captured launch keeps the shape it was captured with, and the
+    first adaptive call on a device allocates its 512 bytes of pinned memory."""
     r = int(options.tile_radius)
-    if r == _lib.RADIUS_AUTO and (options.deterministic or torch.are_deterministic_algorithms_enabled()):
+    if r == _lib.RADIUS_AUTO and (
+            options.deterministic or torch.are_deterministic_algorithms_enabled()
+            or (torch.cuda.is_initialized() and torch.cuda.is_current_stream_capturing())):
         r = _lib.RADIUS_DEFAULT
     return r
 
@@ -395,7 +399,7 @@ def suggest_tile_radius(offset_y, offset_x) -> int:
     """A fixed ``tile_radius`` for offsets like these -- ONE host synchronisation (``.item()``) and a
     pass over both tensors; for callers who want a fixed radius (bit-reproducible forward).  The
     default ``options.tile_radius`` (adaptive) needs neither.  8 when every whole-pixel offset stays
-    within 8, 14 within 14, else 24 (DESIGN.md 4.10).  (A large but uniform displacement -- a pan --
+    within 8, 14 within 14, else 24 (DESIGN.md 4.4).  (A large but uniform displacement -- a pan --
     would run as fast at 8: the scalar cannot tell it from a steep flow; the adaptive mode can.)"""
     reach = int(offset_radius(offset_y, offset_x).item())
     return 8 if reach <= 8 else (14 if reach <= 14 else 24)

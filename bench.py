@@ -274,9 +274,21 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def recorded_traffic(key, batch):
+def kernel_shape(lib, radius, h, w, head=False):
+    """Which kernel shape a launch with `radius` runs: "lean", "14", "24", ... (adaptive: the
+    library's current choice for this tensor shape)."""
+    if radius == _lib.RADIUS_AUTO:
+        radius = adaptive_state(lib, h, w, head)["radius"]
+        return "lean" if radius == 8 else str(radius)
+    if radius == _lib.RADIUS_SMALL:
+        return "lean"
+    return "14" if radius == _lib.RADIUS_DEFAULT else str(radius)
+
+
+def recorded_traffic(key, batch, shape):
     """HBM bytes per launch from the rocprofv3 PMC passes recorded in profiles/pmc_traffic.json
-    (counters cannot be read inside this process); None unless recorded for these kernel sources."""
+    (counters cannot be read inside this process); None unless recorded for these kernel sources
+    and this kernel shape."""
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         rec = json.load(open(tpath))
@@ -284,6 +296,8 @@ def recorded_traffic(key, batch):
         return None, None
     if rec.get("source_hash") != source_hash():
         return None, "profiles/pmc_traffic.json was recorded for other kernel sources"
+    if rec.get("shape", "14") != shape:
+        return None, f"profiles/pmc_traffic.json holds the {rec.get('shape', '14')} shape, this run used {shape}"
     v = rec.get(key)
     return (None if v is None else int(v) * batch), "profiles/pmc_traffic.json (rocprofv3 --pmc, recorded)"
 
@@ -362,6 +376,17 @@ def regime_timing(lib, device, B, radius, stream, regime, steps, headline_mpix):
     return res
 
 
+def warm_up(step, n, radius):
+    """n untimed steps.  Under the adaptive radius the first two are each followed by a
+    synchronisation: the library picks a shape's radius when a launch is ENQUEUED, from what the
+    launches that have FINISHED reported, so n steps enqueued in one go would all run at the start
+    radius (14) and the timed region would begin with kernels that never ran."""
+    for i in range(n):
+        step()
+        if radius == _lib.RADIUS_AUTO and i < 2:
+            torch.cuda.synchronize()
+
+
 def run_train(args, rank, world, device, dist, backend):
     lib = _lib.load()  # raises if the HIP library is missing: there is no fallback
     B = args.batch
@@ -374,8 +399,7 @@ def run_train(args, rank, world, device, dist, backend):
             dist.barrier()
 
     events = []
-    for _ in range(args.warmup):
-        op.step()
+    warm_up(op.step, args.warmup, args.radius)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -399,9 +423,10 @@ def run_train(args, rank, world, device, dist, backend):
     bwd_ms = sum(b.elapsed_time(c) for _, b, c in events) / (len(events) * FRAMES)
     bwd_gbs = BWD_BYTES * B * H * W / (bwd_ms * 1e-3) / 1e9
     fwd_gbs = FWD_BYTES * B * H * W / (fwd_ms * 1e-3) / 1e9
-    traffic, traffic_src = recorded_traffic("synth_bwd_bytes_per_launch", B)
-    if args.radius not in (-1, -2) or args.sigma != 1.0:  # (recorded at the default radius, sigma 1)
-        traffic, traffic_src = None, "profiles/pmc_traffic.json holds the default radius at sigma 1 only"
+    traffic, traffic_src = recorded_traffic("synth_bwd_bytes_per_launch", B,
+                                            kernel_shape(lib, args.radius, H, W))
+    if args.sigma != 1.0:  # (recorded at sigma 1)
+        traffic, traffic_src = None, "profiles/pmc_traffic.json holds sigma 1 only"
     line = {
         "metric": "synthesized Mpix/s fwd+bwd (4 frames, 1080p)",
         "value": round(value, 2),
@@ -472,13 +497,14 @@ def config2_fwd_bytes():
     return (3 * K_TAPS * 4 + C * 4) * n2 * h2 * w2 + C * 4 * n2 * (h2 + 2 * PAD) * (w2 + 2 * PAD)
 
 
-def config2_gpu_quick(lib, device, radius, stream, sigma, steps=10):
+def config2_gpu_quick(lib, device, radius, stream, sigma, steps=100, warmup=50):
     """configs[1] on the GPU beside the headline (the full line: --workload config2): 4 forward
-    launches of N = 16 x 256 x 448 per step, HIP events."""
+    launches of N = 16 x 256 x 448 per step, HIP events.  50 + 100 steps of 0.4 ms: the first ~50 ms
+    after a pause run up to 15 % slower (profiles/r3_sustained.log)."""
     n2, h2, w2 = CONFIG2_SHAPE
     frames = make_frames(n2, sigma, device, seed=503, size=(h2, w2), backward=False)
     op = Op(lib, frames, n2, radius, stream, size=(h2, w2))
-    for _ in range(3):
+    for _ in range(warmup):
         for f in frames:
             op.fwd(f)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -520,8 +546,7 @@ def run_config2(args, rank, world, device, dist, backend):
         if dist is not None:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
+    warm_up(step, args.warmup, args.radius)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -611,8 +636,7 @@ def run_interp7(args, rank, world, device, dist, backend):
         if dist is not None:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
+    warm_up(step, args.warmup, args.radius)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -635,8 +659,9 @@ def run_interp7(args, rank, world, device, dist, backend):
     kernel_ms = e0.elapsed_time(e1) / args.steps
     value = TS * H * W / (ms * 1e-3) / 1e6
     # recorded for one 1080p sample (tools/prof_run.py --head); this launch holds n samples of Hl rows
-    traffic, traffic_src = recorded_traffic("head_fwd_bytes_per_launch", 1)
-    if traffic is not None and args.radius in (-1, -2):
+    traffic, traffic_src = recorded_traffic("head_fwd_bytes_per_launch", 1,
+                                            kernel_shape(lib, args.radius, Hl, W, head=True))
+    if traffic is not None and args.sigma == 1.0:
         traffic = int(traffic * n * Hl / H)
     else:
         traffic = None
@@ -672,8 +697,12 @@ def run_interp7(args, rank, world, device, dist, backend):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default: 20 for train, 200 for config2, 60 for interp7 -- the short "
+                         "steps of the latter two need ~100 ms of sustained launches before the rate "
+                         "settles, profiles/r3_sustained.log)")
+    ap.add_argument("--warmup", type=int, default=None,
+                    help="untimed steps first (default: 5 / 100 / 20)")
     ap.add_argument("--workload", choices=["train", "config2", "interp7"], default="train",
                     help="train = the headline (op fwd+bwd, 4 frames, 1080p); config2 = configs[1] (op "
                          "forward, N=16 x 256x448, 4 frames); interp7 = configs[3]")
@@ -692,6 +721,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-head", action="store_true", help="skip the fused-head side measurement")
     args = ap.parse_args()
+    default_steps, default_warmup = {"train": (20, 5), "config2": (200, 100), "interp7": (60, 20)}[args.workload]
+    if args.steps is None:
+        args.steps = default_steps
+    if args.warmup is None:
+        args.warmup = default_warmup
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -61,3 +61,28 @@ def test_head_forward_backward_replays_from_a_hip_graph():
     torch.cuda.synchronize()
     for got, ref in zip((out, gw, ga, gb, gocc), want):
         assert torch.equal(got, ref)
+
+
+@pytest.mark.adaptive
+def test_operator_under_capture_with_the_adaptive_default_uses_the_fixed_radius(oracle):
+    """options.tile_radius is adaptive by default; a captured launch keeps the shape it was captured
+    with and the first adaptive call on a device allocates, so under capture the wrapper passes the
+    fixed default: the replay is bit-identical to an eager call at radius -1."""
+    import artemis_amd
+    from artemis_amd import _lib
+    from conftest import make_operands, parity_close
+    assert artemis_amd.options.tile_radius == _lib.RADIUS_AUTO
+    dev = torch.device("cuda:0")
+    inp, w, oy, ox, _ = make_operands(1, 3, 40, 72, regime="gauss1", seed=11)
+    t = [torch.from_numpy(x).to(dev) for x in (inp, w, oy, ox)]
+    with artemis_amd.synth_options(tile_radius=_lib.RADIUS_DEFAULT):
+        want = artemis_amd.FunctionSynth.apply(*t, 1)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = artemis_amd.FunctionSynth.apply(*t, 1)
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    parity_close(out, oracle.forward(inp, w, oy, ox, 1), 1e-5, "output, captured")

@@ -1,4 +1,4 @@
-"""Large coherent motion: the LDS tile re-centres on the tile's mean displacement (DESIGN.md 4.8c).
+"""Large coherent motion: the LDS tile re-centres on the tile's mean displacement (DESIGN.md 4.3).
 Parity against the oracle where every tile is shifted, where the shift varies across the frame and
 where it pushes the window across the frame borders."""
 import numpy as np

@@ -103,7 +103,7 @@ def test_interpolation_row_strips_reproduce_the_whole_frame_on_gpu(world):
 @pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 8])
 def test_interpolation_row_strips_on_a_steep_flow_agree_to_rounding(world):
-    """The documented other half (INTEGRATION.md 4, DESIGN.md 4.8c): on large steep motion (the
+    """The documented other half (INTEGRATION.md 4, DESIGN.md 4.3): on large steep motion (the
     bench's smooth30 field) windows are re-centred and staged again per TILE, tile origins are
     relative to the strip, so the ranks' strips equal the single launch to the forward tolerance,
     not bit for bit."""

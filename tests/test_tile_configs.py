@@ -42,7 +42,7 @@ def may_recentre(regime, radius):
     radius; which taps take the fix-up (hence a pixel's last bit) then depends on the tiling.  (The
     other per-tile decision, a further window after the vote, needs >= 24 pixels of a window whose
     unserved taps share a displacement: the i.i.d. regimes used here never pass its one-third rule,
-    their stray taps go through fix-up form (a), which is per pixel -- DESIGN.md 4.8c.)"""
+    their stray taps go through fix-up form (a), which is per pixel -- DESIGN.md 4.3.)"""
     R = {-1: 14, -3: 8}.get(radius, radius)    # the fixed default; RADIUS_SMALL = 8 in the lean shape
     mean_std = {"init": 0.01, "gauss1": 0.2, "gauss4": 0.8, "uniform3": 0.35, "integer": 0.4,
                 "clamp40": 4.6, "zero": 0.0}[regime]

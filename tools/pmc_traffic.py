@@ -5,7 +5,9 @@ MI355X_MICROARCH.md (HBM section) prescribes -- FETCH_SIZE counts KiB and, on gf
 streamed bytes; the factor is calibrated on a kernel of known traffic in the product's own access
 pattern (tools/pmc_calib.py under the same two passes).
 
-usage: python tools/pmc_traffic.py <pmc dir of prof_run.py> <pmc dir of pmc_calib.py> [note]
+usage: python tools/pmc_traffic.py <pmc dir of prof_run.py> <pmc dir of pmc_calib.py> [note] [shape]
+(shape: the kernel shape prof_run.py ran -- "lean" for --radius -3, the adaptive default's choice at
+sigma 1; "14" for --radius -1 -- bench.py quotes the record only for launches of that shape)
 """
 import collections
 import csv
@@ -35,6 +37,7 @@ def means(root, needle):
 def main():
     run_dir, calib_dir = sys.argv[1], sys.argv[2]
     note = sys.argv[3] if len(sys.argv) > 3 else ""
+    shape = sys.argv[4] if len(sys.argv) > 4 else "lean"
     import bench
     plane_kib = 75 * H * W * 4 / 1024.0
     cal = means(calib_dir, "stream")
@@ -46,8 +49,9 @@ def main():
     out = {
         "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/pmc_passes.sh), means "
                   "over the launches of tools/prof_run.py (4 rotating 1080p operand sets, sigma 1, "
-                  "library default radius), MI355X. " + note,
+                  "kernel shape '" + shape + "'), MI355X. " + note,
         "source_hash": bench.source_hash(),
+        "shape": shape,
         "units": "FETCH_SIZE/WRITE_SIZE count KiB; gfx950 FETCH_SIZE reads 1/2 of streamed bytes "
                  "(MI355X_MICROARCH.md, HBM section)",
         "calibration": {
