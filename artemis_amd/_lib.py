@@ -40,6 +40,7 @@ SIGNATURES = {
     "artemis_synth_set_small_grid_tiles": (ctypes.c_longlong, [ctypes.c_longlong]),
     "artemis_synth_auto_query": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "artemis_synth_auto_reset": (None, []),
+    "artemis_synth_set_gin_gather": (_i, [_i]),
     "artemis_synth_version": (ctypes.c_char_p, []),
     "artemis_synth_last_error": (ctypes.c_char_p, []),
 }

@@ -72,7 +72,7 @@ void launch_head_bwd(const float *w, const float *oy, const float *ox, const flo
                      float *goy, float *gox, const Geom &g, const HeadArgs &ha, bool lean, hipStream_t st);
 template <int R, bool FIXED>
 void launch_gin_tiled(const float *w, const float *oy, const float *ox, const float *gout, float *gin,
-                      unsigned char *ws, const Geom &g, int bits, hipStream_t st);
+                      unsigned char *ws, const Geom &g, int bits, int guarded, hipStream_t st);
 
 // Grids with fewer 64 x 32 tiles than this run with 64 x 8 tiles (synth_tiles.hip); process-wide
 // tuning knob, set through artemis_synth_set_small_grid_tiles (defined in synth_kernels.hip).
@@ -409,6 +409,13 @@ __global__ __launch_bounds__(256) void synth_gin_atomic_direct(const float *__re
 // ------------------------------------------------------------------------------------------
 
 constexpr size_t kDetHeaderBytes = 256;
+// Workspace header words beyond the two maxima (synth_gin_gather.hpp): word kGaFlagWord is raised to
+// kOneBits (the bits of 1.0f) by gradInput's gather kernel when it meets an offset that does not
+// truncate to zero -- it then gives up, and the scatter kernels, launched behind it with `guarded`,
+// do the work; while the word is 0 they leave at once.  Words kGaQueueWord .. + 7: the gather
+// kernel's per-XCD tile counters.
+constexpr unsigned kOneBits = 0x3f800000u;
+constexpr int kGaFlagWord = 2, kGaQueueWord = 4;
 
 // max |v| of two tensors in one launch (bit patterns of |v| order like the values), for the
 // fixed-point scale of gradInput: slot[0] <- a, slot[1] <- b.  Blocks [0, blocks_a) stream `a`,
@@ -420,8 +427,9 @@ __device__ __forceinline__ unsigned absbits(float v) { return __float_as_uint(v)
 __global__ __launch_bounds__(256) void absmax2_kernel(const float *__restrict__ a, size_t na,
                                                        const float *__restrict__ b, size_t nb,
                                                        unsigned blocks_a, int vec,
-                                                       unsigned *__restrict__ slot)
+                                                       unsigned *__restrict__ slot, int guarded)
 {
+    if (guarded && slot[kGaFlagWord] < kOneBits) return;  // gradInput came from the gather kernel: no scale needed
     const bool first = blockIdx.x < blocks_a;
     const float *v = first ? a : b;
     const size_t count = first ? na : nb;
@@ -533,8 +541,9 @@ __global__ __launch_bounds__(256) void synth_gin_fixed_direct(const float *__res
 
 __global__ __launch_bounds__(256) void det_finalize_kernel(const unsigned char *__restrict__ ws,
                                                             float *__restrict__ gin, size_t count,
-                                                            int count_bits)
+                                                            int count_bits, int guarded)
 {
+    if (guarded && ((const unsigned *)ws)[kGaFlagWord] < kOneBits) return;  // the gather kernel wrote gradInput
     const double inv = ldexp(1.0, -det_scale_log2((const unsigned *)ws, count_bits));  // exact
     const long long *accum = (const long long *)(ws + kDetHeaderBytes);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
@@ -660,22 +669,36 @@ __device__ __forceinline__ bool tap_in_tile(float a, float b, Centre c)
 // Any value is correct; a representative one keeps the taps in the tile.  The tile is moved only
 // when that mean exceeds half the radius: for ordinary offsets the centre stays 0 and which taps
 // take the fix-up -- hence the last bit of a pixel -- does not depend on how the frame is tiled.
-template <int R>
-__device__ __forceinline__ Centre tile_centre(const float *__restrict__ ab,
-                                              const float *__restrict__ bb, size_t plane,
-                                              const Geom &g, int tx0, int ty0, int th, int tw = 64)
+// The gather and its evaluation are separate so that the fused head can fetch frame f + 1's operands
+// while frame f's taps run (SYNTH_CENTRE_AHEAD): the window fill waits for the centre, and behind a
+// busy memory system that dependent round trip was 3.5 % of the lean head's forward.
+struct CentreProbe {
+    float a, b;  // lane l < 25: the offsets of tap l at the window's middle pixel
+};
+
+__device__ __forceinline__ CentreProbe centre_probe(const float *__restrict__ ab,
+                                                    const float *__restrict__ bb, size_t plane,
+                                                    const Geom &g, int tx0, int ty0, int th, int tw = 64)
 {
-    Centre c = {0.f, 0.f};
+    CentreProbe p = {0.f, 0.f};
 #if SYNTH_CENTRE
     const int l = threadIdx.x & 63;
     const size_t pix = (size_t)min(ty0 + th / 2, g.H - 1) * g.W + min(tx0 + tw / 2, g.W - 1);
-    float a = 0.f, b = 0.f;
     if (l < 25) {
-        a = ab[(size_t)l * plane + pix];
-        b = bb[(size_t)l * plane + pix];
+        p.a = ab[(size_t)l * plane + pix];
+        p.b = bb[(size_t)l * plane + pix];
     }
-    a = rintf(wave_sum(a) * (1.f / 25.f));
-    b = rintf(wave_sum(b) * (1.f / 25.f));
+#endif
+    return p;
+}
+
+template <int R>
+__device__ __forceinline__ Centre centre_of(CentreProbe p)
+{
+    Centre c = {0.f, 0.f};
+#if SYNTH_CENTRE
+    const float a = rintf(wave_sum(p.a) * (1.f / 25.f));
+    const float b = rintf(wave_sum(p.b) * (1.f / 25.f));
     c.y = (fabsf(a) < 1.0e6f && fabsf(a) > 0.5f * R) ? a : 0.f;  // NaN / inf / absurd: no centring
     c.x = (fabsf(b) < 1.0e6f && fabsf(b) > 0.5f * R) ? b : 0.f;
     c.y = __builtin_amdgcn_readfirstlane(c.y);
@@ -683,6 +706,18 @@ __device__ __forceinline__ Centre tile_centre(const float *__restrict__ ab,
 #endif
     return c;
 }
+
+template <int R>
+__device__ __forceinline__ Centre tile_centre(const float *__restrict__ ab,
+                                              const float *__restrict__ bb, size_t plane,
+                                              const Geom &g, int tx0, int ty0, int th, int tw = 64)
+{
+    return centre_of<R>(centre_probe(ab, bb, plane, g, tx0, ty0, th, tw));
+}
+
+#ifndef SYNTH_CENTRE_AHEAD  // (0: every frame of the head gathers its centre when it starts -- for A/B builds)
+#define SYNTH_CENTRE_AHEAD 1
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Several windows per tile.  One window follows ONE motion; a tile that straddles a motion
@@ -1480,6 +1515,8 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
 
     const int T = HEAD ? ha.T : 1;
     bool tile_free = true;  // no wave will read the staged windows again before the next barrier
+    constexpr bool kAhead = SYNTH_CENTRE_AHEAD && HEAD && PASSES == 1;
+    CentreProbe ahead = {0.f, 0.f};
     for (int f = 0; f < T; ++f) {
         size_t pl = plane, rf[ROWS];
 #pragma unroll
@@ -1604,7 +1641,9 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
                 fwd_outside_steps<ROWS>(ip, wb + x, ab + x, bb + x, g, sm, rf, rowy, x, acc0, acc1, acc2);
         };
 
-        Windows win = one_window(tile_centre<R>(ab, bb, pl, g, sx0, ty0, TH, SW));
+        // (the lean head: this frame's centre operands were fetched while the previous frame's taps ran)
+        Windows win = one_window((kAhead && f > 0) ? centre_of<R>(ahead)
+                                                   : tile_centre<R>(ab, bb, pl, g, sx0, ty0, TH, SW));
         Centre ctr = win.c0;
         unsigned long long flagged[ROWS];
         bool mine = true;  // this wave's window is (re)staged in the coming pass
@@ -1621,14 +1660,27 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
             // every wave is done with the previous window (frame f - 1's last one; within a frame
             // the vote's barrier has already seen to that -- and when frame f - 1 ended on a vote
             // that asked for no further pass, so has that barrier: no wave reads a window after it)
+#ifdef SYNTH_DEV_NOFILL  // timing experiment only (wrong results): the head stages frame 0's window alone
+            if (!HEAD || f == 0) {
+#endif
             if (HEAD && f > 0 && p == 0 && !(SYNTH_HEAD_SYNC_DEDUPE && tile_free)) __syncthreads();
             if (mine)
                 fill_tile_n<R, TH, 64 * (WAVES / NWIN), SW>(tile, ip, g, ty0 + g.oy0 - R + (int)ctr.y,
                                                             sx0 + g.ox0 - R + (int)ctr.x, tid);
             __syncthreads();
+#ifdef SYNTH_DEV_NOFILL
+            }
+#endif
 #ifdef SYNTH_DEV_TILE_CLOCK
             if (p == 1) dbg_b = wall_clock64();
 #endif
+            if constexpr (kAhead) {
+                if (f + 1 < T) {  // every wave, active or not: each evaluates the centre by itself
+                    const size_t nn = ((size_t)n * T + f + 1) * 25 * pl;
+                    ahead = centre_probe(oy + nn, ox + nn, pl, g, sx0, ty0, TH, SW);
+                    __builtin_amdgcn_sched_barrier(0);  // issued here, not where the values are first used
+                }
+            }
             if (p == 0) {
                 if (active) {
                     run_taps(IntTag<1>{}, ctr);
@@ -1805,10 +1857,12 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
     float d[ROWS][3];
     // max |weight| and max |gradOutput| over this lane's pixels, for the caller's gradInput pass
     // (its fixed-point scale; saves that pass a 53 us sweep over the weights): maxima[0], maxima[1]
-    unsigned mx_w = 0u, mx_g = 0u;
+    unsigned mx_w = 0u, mx_g = 0u;  // max |weight|, max |gradOutput| as bit patterns
 
     const int T = HEAD ? ha.T : 1;
     bool tile_free = true;  // no wave will read the staged windows again before the next barrier
+    constexpr bool kAhead = SYNTH_CENTRE_AHEAD && HEAD && PASSES == 1;
+    CentreProbe ahead = {0.f, 0.f};
     for (int f = 0; f < T; ++f) {
         size_t pl = plane, rf[ROWS];
 #pragma unroll
@@ -1962,7 +2016,9 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
             }
         };
 
-        Windows win = one_window(tile_centre<R>(ab, bb, pl, g, sx0, ty0, TH, SW));
+        // (the lean head: this frame's centre operands were fetched while the previous frame's taps ran)
+        Windows win = one_window((kAhead && f > 0) ? centre_of<R>(ahead)
+                                                   : tile_centre<R>(ab, bb, pl, g, sx0, ty0, TH, SW));
         Centre ctr = win.c0;
         unsigned long long flagged[ROWS];
         bool mine = true;  // this wave's window is (re)staged in the coming pass
@@ -1977,6 +2033,13 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
                 fill_tile_n<R, TH, 64 * (WAVES / NWIN), SW>(tile, ip, g, ty0 + g.oy0 - R + (int)ctr.y,
                                                             sx0 + g.ox0 - R + (int)ctr.x, tid);
             __syncthreads();
+            if constexpr (kAhead) {
+                if (f + 1 < T) {  // (see forward)
+                    const size_t nn = ((size_t)n * T + f + 1) * 25 * pl;
+                    ahead = centre_probe(oy + nn, ox + nn, pl, g, sx0, ty0, TH, SW);
+                    __builtin_amdgcn_sched_barrier(0);  // issued here, not where the values are first used
+                }
+            }
             if (p == 0) {
                 if (active) {
                     if (f == 0) {  // gradOutput is the same for every frame of the head
@@ -2099,8 +2162,9 @@ __global__ __launch_bounds__(64 * WAVES) void synth_gin_tiled(const float *__res
                                                               const float *__restrict__ gout,
                                                               float *__restrict__ gin,
                                                               unsigned char *__restrict__ ws,
-                                                              Geom g, int count_bits)
+                                                              Geom g, int count_bits, int guarded)
 {
+    if (guarded && ((const unsigned *)ws)[kGaFlagWord] < kOneBits) return;  // the gather kernel took this call
     typedef unsigned long long acc_t;
     constexpr int TH = WAVES * ROWS;
     constexpr int LW = TileShape<R, TH>::LW, LH = TileShape<R, TH>::LH;

@@ -16,6 +16,8 @@ long long small_grid_tiles() { return g_small_grid_tiles.load(std::memory_order_
 }  // namespace asynth
 
 namespace {
+#include "synth_gin_gather.hpp"
+std::atomic<int> g_gin_gather{1};  // artemis_synth_set_gin_gather
 
 using asynth::launch_bwd_tiled;
 using asynth::launch_fwd_tiled;
@@ -315,6 +317,11 @@ struct AutoDevice {
     AutoMirror *mirror;            // host view
     AutoMirror *mirror_dev;        // the same memory as the GPU addresses it
     AutoEntry e[kAutoKeys];
+    // gradInput's gather kernel (gather_begin): attempts issued, last give-up report applied
+    // (mirror[0].pad holds the id of the last attempt that gave up), calls still to skip, current
+    // back-off, attempts since the last report
+    unsigned long long ga_seq, ga_seen;
+    int ga_skip, ga_backoff, ga_quiet;
 };
 }  // namespace
 
@@ -473,6 +480,45 @@ void auto_end(const AutoLaunch &a, const Geom &g, int frames, hipStream_t st)
     }
 }
 
+// Should this backward call enqueue gradInput's gather kernel, which only pays when every offset
+// truncates to zero and otherwise gives up after one memory round trip (13-18 us at 1080p)?  Its
+// first workgroup reports a give-up to pinned host memory; after a report the next 1, 2, 4 .. 64
+// calls do without the kernel, then it is tried again -- so a training run whose offsets have grown
+// past a pixel pays for one attempt in 64, and one that is back to small offsets (16 attempts
+// without a report) runs it every time.  The channel is the pinned record of
+// ARTEMIS_SYNTH_RADIUS_AUTO; before a forward call with that radius has set it up on the device
+// (this function never allocates) every call tries.  No synchronisation anywhere: a report may lag
+// by the calls in flight, which costs those attempts, nothing else.
+struct GatherTry {
+    bool attempt;
+    unsigned long long id;
+    unsigned long long *report;
+};
+
+GatherTry gather_begin()
+{
+    GatherTry t{true, 0ull, nullptr};
+    std::lock_guard<std::mutex> lock(g_auto_mutex);
+    AutoDevice *d = auto_device(false);
+    if (!d) return t;
+    const unsigned long long rep = ((volatile AutoMirror *)d->mirror)[0].pad;
+    if (rep > d->ga_seen) {
+        d->ga_seen = rep;
+        d->ga_backoff = d->ga_backoff ? (d->ga_backoff < 32 ? d->ga_backoff * 2 : 64) : 1;
+        d->ga_skip = d->ga_backoff;
+        d->ga_quiet = 0;
+    }
+    if (d->ga_skip > 0) {
+        d->ga_skip -= 1;
+        t.attempt = false;
+        return t;
+    }
+    if (++d->ga_quiet >= 16) d->ga_backoff = 0;
+    t.id = ++d->ga_seq;
+    t.report = &d->mirror_dev[0].pad;
+    return t;
+}
+
 }  // namespace
 
 extern "C" {
@@ -593,6 +639,15 @@ static int run_backward(const Geom &g, int rc, const void *input_any, const floa
     const bool fixed = gin_mode == ARTEMIS_SYNTH_GIN_DETERMINISTIC;
     const size_t need = grad_input ? ws_bytes_needed(g, gin_mode, Rg) : 0;
     unsigned char *ws = (unsigned char *)workspace;
+    // Offsets that all truncate to zero (a freshly initialised model): gradInput in gather form
+    // (synth_gin_gather.hpp).  Whether they do is found out on the device, by the gather kernel itself:
+    // it and the scatter kernels are both enqueued, and the scatter kernels (`guarded`) leave at once
+    // unless the gather kernel gave up.
+    GatherPlan plan;
+    GatherTry gtry{false, 0ull, nullptr};
+    if (grad_input && Rg > 0 && need && g_gin_gather.load(std::memory_order_relaxed) && gather_plan(g, plan))
+        gtry = gather_begin();
+    const int guarded = gtry.attempt ? 1 : 0;
     if (grad_input) {
         if (need && (!workspace || workspace_bytes < need))
             return fail(hipErrorInvalidValue,
@@ -603,7 +658,8 @@ static int run_backward(const Geom &g, int rc, const void *input_any, const floa
             return fail(hipErrorInvalidValue, "artemis_synth_backward: workspace not 16-byte aligned");
         hipError_t e = hipSuccess;
         if (need) e = hipMemsetAsync(ws, 0, need, st);
-        if (e == hipSuccess && !fixed) e = hipMemsetAsync(grad_input, 0, gin_count * sizeof(float), st);
+        if (e == hipSuccess && !fixed && !guarded)
+            e = hipMemsetAsync(grad_input, 0, gin_count * sizeof(float), st);
         if (e != hipSuccess) return fail((int)e, "hipMemsetAsync: %s", hipGetErrorString(e));
     }
     bool have_maxima = false;
@@ -637,6 +693,13 @@ static int run_backward(const Geom &g, int rc, const void *input_any, const floa
 
     if (grad_input) {
         const int bits = count_bits_for(g);
+        if (guarded) {
+            launch_gin_gather(weight, offset_y, offset_x, grad_output, grad_input, g, plan, (unsigned *)ws,
+                              gtry.report, gtry.id, st);
+            if (!fixed)  // (the gather kernel may have stored part of gradInput before it gave up)
+                hipLaunchKernelGGL(zero_if_scatter_kernel, dim3(reduce_blocks(gin_count)), dim3(256), 0, st,
+                                   grad_input, gin_count, (const unsigned *)ws);
+        }
         if (need && !have_maxima) {  // maxima for the fixed-point scale
             const size_t wcount = (size_t)N * k * k * H * W, gcount = (size_t)N * C * H * W;
             // one launch for both maxima; ~16 KB of 16-byte loads per block and pass
@@ -648,18 +711,18 @@ static int run_backward(const Geom &g, int rc, const void *input_any, const floa
             };
             const unsigned ba = blocks_for(wcount), bb = blocks_for(gcount);
             hipLaunchKernelGGL(absmax2_kernel, dim3(ba + bb), dim3(256), 0, st, weight, wcount,
-                               grad_output, gcount, ba, vec, (unsigned *)ws);
+                               grad_output, gcount, ba, vec, (unsigned *)ws, guarded);
         }
         if (Rg > 0) {
             switch (Rg * 2 + (fixed ? 1 : 0)) {
-            case 4: launch_gin_tiled<2, false>(weight, offset_y, offset_x, grad_output, grad_input, ws, g, bits, st); break;
-            case 5: launch_gin_tiled<2, true>(weight, offset_y, offset_x, grad_output, grad_input, ws, g, bits, st); break;
-            case 8: launch_gin_tiled<4, false>(weight, offset_y, offset_x, grad_output, grad_input, ws, g, bits, st); break;
-            case 9: launch_gin_tiled<4, true>(weight, offset_y, offset_x, grad_output, grad_input, ws, g, bits, st); break;
-            case 16: launch_gin_tiled<8, false>(weight, offset_y, offset_x, grad_output, grad_input, ws, g, bits, st); break;
-            case 17: launch_gin_tiled<8, true>(weight, offset_y, offset_x, grad_output, grad_input, ws, g, bits, st); break;
-            case 28: launch_gin_tiled<14, false>(weight, offset_y, offset_x, grad_output, grad_input, ws, g, bits, st); break;
-            default: launch_gin_tiled<14, true>(weight, offset_y, offset_x, grad_output, grad_input, ws, g, bits, st); break;
+            case 4: launch_gin_tiled<2, false>(weight, offset_y, offset_x, grad_output, grad_input, ws, g, bits, guarded, st); break;
+            case 5: launch_gin_tiled<2, true>(weight, offset_y, offset_x, grad_output, grad_input, ws, g, bits, guarded, st); break;
+            case 8: launch_gin_tiled<4, false>(weight, offset_y, offset_x, grad_output, grad_input, ws, g, bits, guarded, st); break;
+            case 9: launch_gin_tiled<4, true>(weight, offset_y, offset_x, grad_output, grad_input, ws, g, bits, guarded, st); break;
+            case 16: launch_gin_tiled<8, false>(weight, offset_y, offset_x, grad_output, grad_input, ws, g, bits, guarded, st); break;
+            case 17: launch_gin_tiled<8, true>(weight, offset_y, offset_x, grad_output, grad_input, ws, g, bits, guarded, st); break;
+            case 28: launch_gin_tiled<14, false>(weight, offset_y, offset_x, grad_output, grad_input, ws, g, bits, guarded, st); break;
+            default: launch_gin_tiled<14, true>(weight, offset_y, offset_x, grad_output, grad_input, ws, g, bits, guarded, st); break;
             }
         } else if (!fixed) {
             if (k == 5 && C == 3)
@@ -678,7 +741,7 @@ static int run_backward(const Geom &g, int rc, const void *input_any, const floa
         }
         if (fixed)
             hipLaunchKernelGGL(det_finalize_kernel, dim3(reduce_blocks(gin_count)), dim3(256), 0, st,
-                               ws, grad_input, gin_count, bits);
+                               ws, grad_input, gin_count, bits, guarded);
         const int e2 = check_launch("artemis_synth_backward (grad_input)");
         if (e2) return e2;
     }
@@ -898,8 +961,20 @@ int artemis_synth_auto_query(int H, int W, int head, int *radius, double *frac8,
 void artemis_synth_auto_reset(void)
 {
     std::lock_guard<std::mutex> lock(g_auto_mutex);
-    if (AutoDevice *d = auto_device(false))
+    if (AutoDevice *d = auto_device(false)) {
         for (int i = 0; i < kAutoKeys; ++i) d->e[i].used = false;
+        d->ga_skip = d->ga_backoff = d->ga_quiet = 0;
+    }
+}
+
+int artemis_synth_set_gin_gather(int enable)
+{
+    if (enable < 0) return g_gin_gather.load(std::memory_order_relaxed);
+    {  // (a change of the setting also forgets the current device's back-off: the next call tries)
+        std::lock_guard<std::mutex> lock(g_auto_mutex);
+        if (AutoDevice *d = auto_device(false)) d->ga_skip = d->ga_backoff = d->ga_quiet = 0;
+    }
+    return g_gin_gather.exchange(enable ? 1 : 0, std::memory_order_relaxed);
 }
 
 long long artemis_synth_set_small_grid_tiles(long long tiles)

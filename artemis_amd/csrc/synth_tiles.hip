@@ -268,13 +268,13 @@ void launch_head_bwd(const float *w, const float *oy, const float *ox, const flo
 // 114 KB at R = 14: one workgroup per CU)
 template <int R, bool FIXED>
 void launch_gin_tiled(const float *w, const float *oy, const float *ox, const float *gout, float *gin,
-                      unsigned char *ws, const Geom &g, int bits, hipStream_t st)
+                      unsigned char *ws, const Geom &g, int bits, int guarded, hipStream_t st)
 {
     // 64 x 16 tiles; at the largest radius the tile takes most of the LDS (one workgroup per CU), so it
     // gets 8 waves of 2 rows instead of 4 waves of 4 rows (415 -> 385 us at 1080p)
     constexpr int WAVES = R > 8 ? 8 : 4, ROWS = R > 8 ? 2 : 4;
     hipLaunchKernelGGL((synth_gin_tiled<R, WAVES, ROWS, FIXED>), pixel_grid(g, WAVES * ROWS),
-                       dim3(64, WAVES), 0, st, w, oy, ox, gout, gin, ws, g, bits);
+                       dim3(64, WAVES), 0, st, w, oy, ox, gout, gin, ws, g, bits, guarded);
 }
 
 
@@ -309,10 +309,10 @@ template void launch_head_bwd<SYNTH_TILE_R, frame_t>(const float *, const float 
 #if !SYNTH_TILE_BF16 && SYNTH_TILE_R <= 14  // (gradInput's 64-bit accumulator window tops out at R = 14)
 template void launch_gin_tiled<SYNTH_TILE_R, false>(const float *, const float *, const float *,
                                                     const float *, float *, unsigned char *,
-                                                    const Geom &, int, hipStream_t);
+                                                    const Geom &, int, int, hipStream_t);
 template void launch_gin_tiled<SYNTH_TILE_R, true>(const float *, const float *, const float *,
                                                    const float *, float *, unsigned char *,
-                                                   const Geom &, int, hipStream_t);
+                                                   const Geom &, int, int, hipStream_t);
 #endif
 #endif  // SYNTH_DEV_ONLY_FWD
 

@@ -714,7 +714,7 @@ def main():
     ap.add_argument("--radius", type=int, default=_lib.RADIUS_AUTO,
                     help="LDS tile radius passed to the library; -2 = adaptive (the package default), "
                          "-1 = the fixed library default (14)")
-    ap.add_argument("--regimes", default="smooth30,sigma:4,pan,sigma:1@14,smooth30@14",
+    ap.add_argument("--regimes", default="smooth30,sigma:4,pan,sigma:1@14,sigma:1@24,smooth30@14",
                     help="other offset regimes timed beside the headline at N = 1 ('' = none); "
                          "'<regime>@<r>' = at the FIXED tile radius r")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, host cpus)")

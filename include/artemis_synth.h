@@ -24,8 +24,8 @@
  *    thread-local description of the last failure on the calling thread.  No exception crosses
  *    the boundary.
  *  - entry points are reentrant: forward is called from the user's thread, backward from PyTorch's
- *    autograd thread.  The mutable state of the library is one atomic tuning integer
- *    (artemis_synth_set_small_grid_tiles; never changes results) and, only for callers that pass
+ *    autograd thread.  The mutable state of the library is two atomic tuning integers
+ *    (artemis_synth_set_small_grid_tiles, artemis_synth_set_gin_gather) and, only for callers that pass
  *    ARTEMIS_SYNTH_RADIUS_AUTO, a mutex-guarded table of per-shape radii (see there).
  *  - empty problems (N, H or W equal to 0) are a successful no-op.
  *  - limits: one (H*W) plane and one padded frame plane must each hold fewer than 2^31
@@ -248,6 +248,23 @@ int artemis_synth_offset_radius(const float *offset_y, const float *offset_x, si
 int artemis_synth_auto_query(int H, int W, int head, int *radius, double *frac8, double *frac14,
                              unsigned long long *forward_calls);
 void artemis_synth_auto_reset(void);
+
+/* gradInput in gather form.  When artemis_synth_backward* is asked for grad_input (k = 5, d = 1, C = 3,
+ * tile_radius != NONE, a frame of at least 32 x 64 texels whose origin lies at most 3 rows / columns
+ * outside it) and every offset truncates to zero -- |offset| < 1 everywhere: a freshly initialised
+ * model -- grad_input is summed per texel in registers in a fixed order instead of scattered through
+ * atomics: bit-reproducible in either gin_mode and faster.  Whether the offsets
+ * qualify is found out on the device: the gather kernel runs first, checks every offset it loads and
+ * gives up at the first that reaches 1 (raising word 2 of the workspace header, which is 0 after a
+ * call that the gather kernel completed); the scatter kernels are enqueued behind it and leave at
+ * once unless it gave up.  No host synchronisation.  Giving up costs 13-18 us per 1080p frame; the
+ * kernel's first workgroup reports it through the pinned record of ARTEMIS_SYNTH_RADIUS_AUTO (when a
+ * forward call with that radius has set it up on the device), after which the next 1, 2, 4 .. 64
+ * backward calls do not enqueue the kernel before it is tried again.
+ * artemis_synth_set_gin_gather(0) turns the path off, (1) on (returns the previous setting and
+ * forgets the back-off; a negative argument only queries).  No reference counterpart (upstream has
+ * no grad_input). */
+int artemis_synth_set_gin_gather(int enable);
 
 /* Process-wide tuning knob (one atomic integer): problems
  * with fewer than `tiles` workgroup tiles of 64 x 32 pixels (N * ceil(W/64) * ceil(H/32)) run with
