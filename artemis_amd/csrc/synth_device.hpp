@@ -669,36 +669,22 @@ __device__ __forceinline__ bool tap_in_tile(float a, float b, Centre c)
 // Any value is correct; a representative one keeps the taps in the tile.  The tile is moved only
 // when that mean exceeds half the radius: for ordinary offsets the centre stays 0 and which taps
 // take the fix-up -- hence the last bit of a pixel -- does not depend on how the frame is tiled.
-// The gather and its evaluation are separate so that the fused head can fetch frame f + 1's operands
-// while frame f's taps run (SYNTH_CENTRE_AHEAD): the window fill waits for the centre, and behind a
-// busy memory system that dependent round trip was 3.5 % of the lean head's forward.
-struct CentreProbe {
-    float a, b;  // lane l < 25: the offsets of tap l at the window's middle pixel
-};
-
-__device__ __forceinline__ CentreProbe centre_probe(const float *__restrict__ ab,
-                                                    const float *__restrict__ bb, size_t plane,
-                                                    const Geom &g, int tx0, int ty0, int th, int tw = 64)
-{
-    CentreProbe p = {0.f, 0.f};
-#if SYNTH_CENTRE
-    const int l = threadIdx.x & 63;
-    const size_t pix = (size_t)min(ty0 + th / 2, g.H - 1) * g.W + min(tx0 + tw / 2, g.W - 1);
-    if (l < 25) {
-        p.a = ab[(size_t)l * plane + pix];
-        p.b = bb[(size_t)l * plane + pix];
-    }
-#endif
-    return p;
-}
-
 template <int R>
-__device__ __forceinline__ Centre centre_of(CentreProbe p)
+__device__ __forceinline__ Centre tile_centre(const float *__restrict__ ab,
+                                              const float *__restrict__ bb, size_t plane,
+                                              const Geom &g, int tx0, int ty0, int th, int tw = 64)
 {
     Centre c = {0.f, 0.f};
 #if SYNTH_CENTRE
-    const float a = rintf(wave_sum(p.a) * (1.f / 25.f));
-    const float b = rintf(wave_sum(p.b) * (1.f / 25.f));
+    const int l = threadIdx.x & 63;
+    const size_t pix = (size_t)min(ty0 + th / 2, g.H - 1) * g.W + min(tx0 + tw / 2, g.W - 1);
+    float a = 0.f, b = 0.f;
+    if (l < 25) {
+        a = ab[(size_t)l * plane + pix];
+        b = bb[(size_t)l * plane + pix];
+    }
+    a = rintf(wave_sum(a) * (1.f / 25.f));
+    b = rintf(wave_sum(b) * (1.f / 25.f));
     c.y = (fabsf(a) < 1.0e6f && fabsf(a) > 0.5f * R) ? a : 0.f;  // NaN / inf / absurd: no centring
     c.x = (fabsf(b) < 1.0e6f && fabsf(b) > 0.5f * R) ? b : 0.f;
     c.y = __builtin_amdgcn_readfirstlane(c.y);
@@ -707,16 +693,16 @@ __device__ __forceinline__ Centre centre_of(CentreProbe p)
     return c;
 }
 
-template <int R>
-__device__ __forceinline__ Centre tile_centre(const float *__restrict__ ab,
-                                              const float *__restrict__ bb, size_t plane,
-                                              const Geom &g, int tx0, int ty0, int th, int tw = 64)
-{
-    return centre_of<R>(centre_probe(ab, bb, plane, g, tx0, ty0, th, tw));
-}
-
-#ifndef SYNTH_CENTRE_AHEAD  // (0: every frame of the head gathers its centre when it starts -- for A/B builds)
-#define SYNTH_CENTRE_AHEAD 1
+// The LEAN shape (PASSES == 1: one window, staged once) does not centre its window at all: it is
+// the shape for offsets that stay within its radius of the PIXEL, and leaving the centre out --
+// the 25-lane gather in front of every window fill, the subtractions in the tap loop -- is worth
+// 3.7 % of the fused head's forward (419 -> 403 us at 1080p; per-frame forward 110 -> 108,
+// backward 240 -> 238).  Fetching the next frame's centre while the current frame's taps run did
+// not recover that (422 us).  A pan or any other coherent motion beyond the radius sends
+// ARTEMIS_SYNTH_RADIUS_AUTO to the radius-14 shape, whose windows follow it: the reach statistic
+// that selects the lean shape is measured from the pixel, not from a window centre.
+#ifndef SYNTH_LEAN_CENTRE
+#define SYNTH_LEAN_CENTRE 0
 #endif
 
 // ------------------------------------------------------------------------------------------
@@ -1515,8 +1501,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
 
     const int T = HEAD ? ha.T : 1;
     bool tile_free = true;  // no wave will read the staged windows again before the next barrier
-    constexpr bool kAhead = SYNTH_CENTRE_AHEAD && HEAD && PASSES == 1;
-    CentreProbe ahead = {0.f, 0.f};
+    constexpr bool kCentred = SYNTH_LEAN_CENTRE || PASSES > 1;  // (the lean shape: see SYNTH_LEAN_CENTRE)
     for (int f = 0; f < T; ++f) {
         size_t pl = plane, rf[ROWS];
 #pragma unroll
@@ -1591,7 +1576,11 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
                     bool near = reach <= (float)R;
                     if constexpr (FIRST) {
                         fmask[j] |= near ? 0u : 1u << t;
-                        if (j == 0 && R >= 8) reach_cnt += (reach > 8.f ? 1u : 0u) + (reach > 14.f ? 0x10000u : 0u);
+                        // (beyond 8: from the PIXEL -- what the lean shape, which has no centre, would
+                        // see; beyond 14: from this window's centre -- what radius 14 leaves over)
+                        if (j == 0 && R >= 8)
+                            reach_cnt += (fmaxf(fabsf((float)ia), fabsf((float)ib)) > 8.f ? 1u : 0u) +
+                                         (reach > 14.f ? 0x10000u : 0u);
                     } else {
                         near = near && ((fmask[j] >> t) & 1u);
                         fmask[j] &= near ? ~(1u << t) : ~0u;
@@ -1641,9 +1630,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
                 fwd_outside_steps<ROWS>(ip, wb + x, ab + x, bb + x, g, sm, rf, rowy, x, acc0, acc1, acc2);
         };
 
-        // (the lean head: this frame's centre operands were fetched while the previous frame's taps ran)
-        Windows win = one_window((kAhead && f > 0) ? centre_of<R>(ahead)
-                                                   : tile_centre<R>(ab, bb, pl, g, sx0, ty0, TH, SW));
+        Windows win = one_window(kCentred ? tile_centre<R>(ab, bb, pl, g, sx0, ty0, TH, SW) : Centre{0.f, 0.f});
         Centre ctr = win.c0;
         unsigned long long flagged[ROWS];
         bool mine = true;  // this wave's window is (re)staged in the coming pass
@@ -1674,13 +1661,6 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_fwd_tapmajor(
 #ifdef SYNTH_DEV_TILE_CLOCK
             if (p == 1) dbg_b = wall_clock64();
 #endif
-            if constexpr (kAhead) {
-                if (f + 1 < T) {  // every wave, active or not: each evaluates the centre by itself
-                    const size_t nn = ((size_t)n * T + f + 1) * 25 * pl;
-                    ahead = centre_probe(oy + nn, ox + nn, pl, g, sx0, ty0, TH, SW);
-                    __builtin_amdgcn_sched_barrier(0);  // issued here, not where the values are first used
-                }
-            }
             if (p == 0) {
                 if (active) {
                     run_taps(IntTag<1>{}, ctr);
@@ -1861,8 +1841,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
 
     const int T = HEAD ? ha.T : 1;
     bool tile_free = true;  // no wave will read the staged windows again before the next barrier
-    constexpr bool kAhead = SYNTH_CENTRE_AHEAD && HEAD && PASSES == 1;
-    CentreProbe ahead = {0.f, 0.f};
+    constexpr bool kCentred = SYNTH_LEAN_CENTRE || PASSES > 1;  // (the lean shape: see SYNTH_LEAN_CENTRE)
     for (int f = 0; f < T; ++f) {
         size_t pl = plane, rf[ROWS];
 #pragma unroll
@@ -2016,9 +1995,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
             }
         };
 
-        // (the lean head: this frame's centre operands were fetched while the previous frame's taps ran)
-        Windows win = one_window((kAhead && f > 0) ? centre_of<R>(ahead)
-                                                   : tile_centre<R>(ab, bb, pl, g, sx0, ty0, TH, SW));
+        Windows win = one_window(kCentred ? tile_centre<R>(ab, bb, pl, g, sx0, ty0, TH, SW) : Centre{0.f, 0.f});
         Centre ctr = win.c0;
         unsigned long long flagged[ROWS];
         bool mine = true;  // this wave's window is (re)staged in the coming pass
@@ -2033,13 +2010,6 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void synth_bwd_tapmajor(
                 fill_tile_n<R, TH, 64 * (WAVES / NWIN), SW>(tile, ip, g, ty0 + g.oy0 - R + (int)ctr.y,
                                                             sx0 + g.ox0 - R + (int)ctr.x, tid);
             __syncthreads();
-            if constexpr (kAhead) {
-                if (f + 1 < T) {  // (see forward)
-                    const size_t nn = ((size_t)n * T + f + 1) * 25 * pl;
-                    ahead = centre_probe(oy + nn, ox + nn, pl, g, sx0, ty0, TH, SW);
-                    __builtin_amdgcn_sched_barrier(0);  // issued here, not where the values are first used
-                }
-            }
             if (p == 0) {
                 if (active) {
                     if (f == 0) {  // gradOutput is the same for every frame of the head

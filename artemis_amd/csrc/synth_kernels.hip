@@ -278,7 +278,8 @@ void dispatch_head_bwd(int R, const float *w, const float *oy, const float *ox,
 // ARTEMIS_SYNTH_RADIUS_AUTO: the library picks 8, 14 or 24 per (device, H, W, op | head) from what
 // the FORWARD kernels saw on their previous launches -- no host synchronisation anywhere.
 //   device side  the forward kernels count, over a 1/ROWS sample of the pixels, the taps displaced
-//                beyond 8 and beyond 14 whole pixels from their window's centre (synth_device.hpp,
+//                beyond 8 whole pixels from the pixel (what the lean shape, which has no window
+//                centres, would leave over) and beyond 14 from their window's centre (synth_device.hpp,
 //                reach_cnt) and add the counts, one no-return atomic per wave that has any, to the
 //                key's record in `artemis_synth_auto_counters`;
 //   publish      every few AUTO forward launches a one-wave kernel behind the launch sums the record,

@@ -77,12 +77,13 @@ struct BwdCfg {
 
 // The LEAN shape (tile_radius ARTEMIS_SYNTH_RADIUS_SMALL; what ARTEMIS_SYNTH_RADIUS_AUTO runs once the
 // forward kernels have seen practically no tap beyond 8 px of its window's centre): radius 8, the same
-// 128 x 16 tile served by ONE 128-column window staged once -- no per-64-column centres, no vote, no
-// further windows; a stray tap still takes the per-pixel global fix-up, so any offsets are correct.
+// 128 x 16 tile served by ONE 128-column window staged once at the tile's own position -- no centres
+// (SYNTH_LEAN_CENTRE), no vote, no further windows; a stray tap still takes the per-pixel global
+// fix-up, so any offsets are correct.
 // It is round 1's kernel shape: the windows-follow-the-motion machinery costs the i.i.d. small-offset
 // regimes 1-2 % on the per-frame kernels and 10 % on the fused head's forward (1080p, sigma 1, same
-// process, tools/ab.py: head forward 451-466 us with it at radius 8, 441 without the vote, 419-423 in
-// this shape; per-frame forward / backward 113.5 / 242.8 -> 112.1 / 240.2 us).
+// process, tools/ab.py: head forward 451-466 us with it at radius 8, 441 without the vote, 419-423 with
+// one window, 403 without its centre; per-frame forward / backward 113.5 / 242.8 -> 108 / 238 us).
 struct LeanCfg {
     static constexpr int WAVES = 8, WX = 2, ROWS = 4, OCC = 2, NWIN = 1, PASSES = 1;
     // the operand planes through the LDS-DMA ring (synth_device.hpp): window 88 KB + ring 48 KB

@@ -356,8 +356,10 @@ def regime_timing(lib, device, B, radius, stream, regime, steps, headline_mpix):
         radius = int(r)
     frames = make_frames(B, 0.0, device, seed=211, regime=regime)
     op = Op(lib, frames, B, radius, stream)
-    for _ in range(2):          # (the adaptive radius follows the new offsets with the lag of the
-        op.step()               # launches in flight: let two rounds of warm-up complete)
+    # (the adaptive radius follows the new offsets with the lag of the launches in flight, and may
+    # take two moves -- lean -> 24 -> 14 on a pan: let some rounds of warm-up complete)
+    for _ in range(5 if radius == _lib.RADIUS_AUTO else 2):
+        op.step()
         op.step()
         torch.cuda.synchronize()
     ev = []

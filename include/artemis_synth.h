@@ -64,11 +64,13 @@ extern "C" {
 #define ARTEMIS_SYNTH_RADIUS_NONE 0
 /* ARTEMIS_SYNTH_RADIUS_AUTO: the library moves between the radii 8, 14 and 24 by itself, per (device,
  * H, W, per-frame op | fused head), from what the forward kernels of that shape saw on their earlier
- * launches: over a sample of the pixels they count the taps displaced beyond 8 and beyond 14 whole
- * pixels from their window's centre; every few launches a one-wave kernel behind the launch publishes
- * the counts to pinned host memory, and the next AUTO call -- forward, backward or head -- reads
- * them with plain host loads and picks the smallest radius that leaves fewer than 5e-5 (8) / 1.5e-4
- * (14) of the taps to the global fix-up (a factor-two margin before going back down).  No host
+ * launches: over a sample of the pixels they count the taps displaced beyond 8 whole pixels from
+ * the pixel itself and beyond 14 from their window's centre; every few launches a one-wave kernel
+ * behind the launch publishes the counts to pinned host memory, and the next AUTO call -- forward,
+ * backward or head -- reads them with plain host loads and picks the lean radius-8 shape
+ * (ARTEMIS_SYNTH_RADIUS_SMALL, below) when fewer than 5e-5 of the taps lie beyond 8, else 14 when
+ * fewer than 1.5e-4 lie beyond 14 of a window that follows the motion, else 24 (a factor-two margin
+ * before going back down).  No host
  * synchronisation, no extra pass over the offsets.  A new shape starts at the default (14) and
  * follows its offsets with a lag of the launches in flight.  Results are those of the chosen fixed
  * radius: correct for any offsets, equal between radii up to fp32 summation order -- pass a fixed
@@ -79,11 +81,11 @@ extern "C" {
  * Shapes without LDS kernels (k != 5, d != 1, C != 3) treat AUTO as DEFAULT. */
 #define ARTEMIS_SYNTH_RADIUS_AUTO (-2)
 /* ARTEMIS_SYNTH_RADIUS_SMALL: radius 8 in the LEAN shape -- the 128 x 16 tile served by one window that is
- * staged once around the displacement at its middle: no per-64-column centres, no vote, no further
- * windows.  For offsets known to stay within 8 pixels of a tile's common displacement (random
- * initialisation, small or uniform motion); anything else is still correct, through the per-pixel
- * global fix-up, only slow.  It is what AUTO runs once its statistics show practically no tap
- * beyond 8 pixels.  grad_input runs its radius-8 kernel. */
+ * staged once, at the tile's own position: no window centres, no vote, no further windows.  For
+ * offsets known to stay within 8 pixels (random initialisation, small motion); anything else -- a
+ * pan included: the other shapes' windows follow coherent motion, this one's do not -- is still
+ * correct, through the per-pixel global fix-up, only slow.  It is what AUTO runs once its statistics
+ * show practically no tap beyond 8 pixels.  grad_input runs its radius-8 kernel. */
 #define ARTEMIS_SYNTH_RADIUS_SMALL (-3)
 
 /* grad_input accumulation mode of artemis_synth_backward */

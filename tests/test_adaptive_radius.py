@@ -48,9 +48,10 @@ def _operands(dev, N, H, W, regime, seed):
 @pytest.mark.gpu
 @pytest.mark.adaptive
 def test_adaptive_radius_follows_the_offsets_and_keeps_parity(oracle):
-    """One shape, three offset regimes in a row: sigma 1 -> the radius-8 kernels, sigma 4 -> 24,
-    a pan (large but coherent, the windows follow it) -> back to 8; forward and backward against the
-    oracle at every stage, whatever radius the stage happens to run."""
+    """One shape, four offset regimes in a row: sigma 1 -> the lean radius-8 kernels, sigma 4 -> 24,
+    a pan (large but coherent: the lean shape has no window centres, radius 14's windows follow it)
+    -> 14, sigma 1 again -> back to 8; forward and backward against the oracle at every stage,
+    whatever radius the stage happens to run."""
     import artemis_amd
     from artemis_amd import _lib
     dev = torch.device("cuda:0")
@@ -60,14 +61,14 @@ def test_adaptive_radius_follows_the_offsets_and_keeps_parity(oracle):
     H, W = 272, 448
     oracle.set_threads(8)
     seen = []
-    for regime, want in (("sigma:1", 8), ("sigma:4", 24), ("pan", 8)):
+    for regime, want in (("sigma:1", 8), ("sigma:4", 24), ("pan", 14), ("sigma:1", 8)):
         inp, w, oy, ox, gout = _operands(dev, 2, H, W, regime, seed=len(seen))
-        for it in range(12):                                       # the choice lags the launches in flight
+        for it in range(16):                                       # the choice lags the launches in flight
             t = [inp] + [x.clone().requires_grad_(True) for x in (w, oy, ox)]
             out = artemis_amd.FunctionSynth.apply(*t, 1)
             out.backward(gout)
             torch.cuda.synchronize()
-            if it in (0, 11):
+            if it in (0, 15):
                 tag = f"adaptive {regime} call {it}"
                 parity_close(out, oracle.forward(np_(inp), np_(w), np_(oy), np_(ox), 1), FWD_RTOL, tag + " output")
                 _, rgw, rga, rgb = oracle.backward(np_(gout), np_(inp), np_(w), np_(oy), np_(ox), 1,

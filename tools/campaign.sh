@@ -5,7 +5,7 @@ set -u
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r3z
 mkdir -p $O
-timeout -k 10 300 python -u -m pytest tests/test_graph_capture.py tests/test_bench_contract.py tests/test_adaptive_radius.py -x -q -m gpu --timeout 280 --timeout-method thread > $O/tests.log 2>&1 || { echo tests failed; tail -n 30 $O/tests.log; exit 1; }
+timeout -k 10 900 python -u -m pytest tests -x -q -m gpu --timeout 300 --timeout-method thread > $O/tests.log 2>&1 || { echo tests failed; tail -n 30 $O/tests.log; exit 1; }
 tail -n 2 $O/tests.log
 timeout -k 10 300 python bench.py > $O/bench.json 2> $O/bench.err || { echo bench failed; tail -5 $O/bench.err; exit 1; }
 echo bench ok
@@ -13,6 +13,8 @@ timeout -k 10 200 python bench.py --workload interp7 > $O/bench_interp7.json 2> 
 echo interp7 ok
 timeout -k 10 200 python bench.py --workload config2 > $O/bench_config2.json 2> $O/bench_config2.err || { echo config2 failed; tail -5 $O/bench_config2.err; exit 1; }
 echo config2 ok
+timeout -k 10 500 python tools/sweep.py --radii=-3,-1,24 --gin --smooth > $O/sweep_gin.log 2>&1 || { echo sweep failed; tail -5 $O/sweep_gin.log; exit 1; }
+echo sweep ok
 (cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_bench -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-head --regimes "" > $GRAFT_REPO_ROOT/$O/bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/$O/prof_bench.err) || { echo rocprof bench failed; tail -5 $O/prof_bench.err; exit 1; }
 echo rocprof bench ok
 (cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_head -- python3 $GRAFT_REPO_ROOT/tools/prof_run.py --head --gin 1 --radius -3 > $GRAFT_REPO_ROOT/$O/prof_head.log 2>&1) || { echo rocprof head failed; tail -5 $O/prof_head.log; exit 1; }
