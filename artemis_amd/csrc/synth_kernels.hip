@@ -469,8 +469,9 @@ void auto_end(const AutoLaunch &a, const Geom &g, int frames, hipStream_t st)
     std::lock_guard<std::mutex> lock(g_auto_mutex);
     AutoDevice &d = g_auto[a.dev];
     AutoEntry &e = d.e[a.key];
-    // one row in four of every wave is sampled (one in two on small grids: those fractions read high)
-    e.pending += 0.25 * 25.0 * (double)frames * (double)g.N * (double)g.H * (double)g.W;
+    // one row in four of one wave in kReachSample is sampled (one row in two on small grids: those
+    // fractions read high)
+    e.pending += 0.25 / kReachSample * 25.0 * (double)frames * (double)g.N * (double)g.H * (double)g.W;
     e.calls += 1;
     if (e.calls <= 8 || e.calls % 8 == 0) {
         e.seq += 1;
