@@ -54,10 +54,11 @@ extern "C" {
  * choose (14); ARTEMIS_SYNTH_RADIUS_NONE disables LDS staging (direct gathers through L1/L2).
  * Radius 24 is for offsets that may be large or steep (a flow that changes by tens of pixels across
  * a tile, independent displacements of 4-10 px per tap): one window per 64 x 32 tile instead of two
- * per 128 x 16.  Measured per 1080p frame, forward + backward (profiles/r2_sweep_r24.log): 3 % slower
- * than 14 on N(0,1) px offsets (379 vs 368 us), 6 % faster at sigma = 4 px, 1.7x faster on a smooth
- * +-30 px flow (449 vs 770 us); the lean shape (ARTEMIS_SYNTH_RADIUS_SMALL) is 5 % faster than 14 on
- * N(0,1) px (profiles/r3_bench.json).  grad_input's accumulator window stays at 14.  Only k = 5,
+ * per 128 x 16.  Measured, 4 frames x 1080p forward + backward (the final bench line,
+ * profiles/r3_bench.json: config.other_offset_regimes): on N(0,1) px offsets radius 14 runs at 0.934
+ * and radius 24 at 0.912 of the lean shape (ARTEMIS_SYNTH_RADIUS_SMALL: 1491 Mpix/s; round 1's
+ * kernels, which were this shape, 1507); on a smooth +-30 px flow 24 runs at 0.759 and 14 at 0.468.
+ * grad_input's accumulator window stays at 14.  Only k = 5,
  * d = 1, C = 3 (the model's configuration: config.py:26-27) has an LDS-staged kernel; other shapes
  * always gather directly. */
 #define ARTEMIS_SYNTH_RADIUS_DEFAULT (-1)
