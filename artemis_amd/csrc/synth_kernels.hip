@@ -497,6 +497,8 @@ struct GatherTry {
     unsigned long long *report;
 };
 
+constexpr size_t asynth_header_bytes() { return kDetHeaderBytes; }
+
 GatherTry gather_begin()
 {
     GatherTry t{true, 0ull, nullptr};
@@ -659,7 +661,9 @@ static int run_backward(const Geom &g, int rc, const void *input_any, const floa
         if (need && ((uintptr_t)workspace & 15) != 0)
             return fail(hipErrorInvalidValue, "artemis_synth_backward: workspace not 16-byte aligned");
         hipError_t e = hipSuccess;
-        if (need) e = hipMemsetAsync(ws, 0, need, st);
+        // (with the gather kernel in front, the int64 image and gradInput are cleared only if the
+        // scatter kernels get to run: zero_if_scatter_kernel below)
+        if (need) e = hipMemsetAsync(ws, 0, guarded ? asynth_header_bytes() : need, st);
         if (e == hipSuccess && !fixed && !guarded)
             e = hipMemsetAsync(grad_input, 0, gin_count * sizeof(float), st);
         if (e != hipSuccess) return fail((int)e, "hipMemsetAsync: %s", hipGetErrorString(e));
@@ -698,9 +702,15 @@ static int run_backward(const Geom &g, int rc, const void *input_any, const floa
         if (guarded) {
             launch_gin_gather(weight, offset_y, offset_x, grad_output, grad_input, g, plan, (unsigned *)ws,
                               gtry.report, gtry.id, st);
-            if (!fixed)  // (the gather kernel may have stored part of gradInput before it gave up)
+            // what the scatter kernels accumulate into starts at zero (the gather kernel may also have
+            // stored part of gradInput before it gave up)
+            if (!fixed)
                 hipLaunchKernelGGL(zero_if_scatter_kernel, dim3(reduce_blocks(gin_count)), dim3(256), 0, st,
                                    grad_input, gin_count, (const unsigned *)ws);
+            else if (need > asynth_header_bytes())
+                hipLaunchKernelGGL(zero_if_scatter_kernel, dim3(reduce_blocks(gin_count)), dim3(256), 0, st,
+                                   (float *)(ws + asynth_header_bytes()),
+                                   (need - asynth_header_bytes()) / sizeof(float), (const unsigned *)ws);
         }
         if (need && !have_maxima) {  // maxima for the fixed-point scale
             const size_t wcount = (size_t)N * k * k * H * W, gcount = (size_t)N * C * H * W;
