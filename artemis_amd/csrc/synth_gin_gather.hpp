@@ -27,8 +27,9 @@
 // 30 coalesced dword loads prefetched one tap ahead; pixel row i feeds texel row i - 1 through its
 // dy = 0 coefficients and texel row i through its dy = 1 ones.  The planes come about once from HBM
 // (the x - 1 column and the 5th row are L1 / L2 hits): 324 B per texel, the forward's traffic.
-// (Persistent workgroups taking tiles from per-XCD counters -- a 1080p frame is 1088 tiles for 512
-// resident workgroups -- were tried and lost: 204 against 178 us.)
+// (Persistent workgroups taking tiles from per-XCD counters -- a 1080p frame is 1088 tiles for 768
+// resident workgroups, 1.4 rounds -- were tried and lost: 204 against 178 us.  Workgroups of 4 waves,
+// 128 x 8 texels, 1.7 rounds: 178 against 189 us at random init, but 8 us more to give up.)
 //
 // Clamping: a corner index is clamped to the frame, so the texels of the frame's border also collect
 // what falls on the VIRTUAL rows / columns outside it (one row and column past the padded frame in the
