@@ -398,11 +398,12 @@ def offset_radius(offset_y, offset_x) -> torch.Tensor:
 def suggest_tile_radius(offset_y, offset_x) -> int:
     """A fixed ``tile_radius`` for offsets like these -- ONE host synchronisation (``.item()``) and a
     pass over both tensors; for callers who want a fixed radius (bit-reproducible forward).  The
-    default ``options.tile_radius`` (adaptive) needs neither.  8 when every whole-pixel offset stays
-    within 8, 14 within 14, else 24.  (A large but uniform displacement -- a pan --
-    would run as fast at 8: the scalar cannot tell it from a steep flow; the adaptive mode can.)"""
+    default ``options.tile_radius`` (adaptive) needs neither.  The lean radius-8 shape
+    (``RADIUS_SMALL``) when every whole-pixel offset stays within 8, 14 within 14, else 24
+    (DESIGN.md 4.4).  (A large but uniform displacement -- a pan -- runs as fast at 14: the scalar
+    cannot tell it from a steep flow; the adaptive mode can.)"""
     reach = int(offset_radius(offset_y, offset_x).item())
-    return 8 if reach <= 8 else (14 if reach <= 14 else 24)
+    return _lib.RADIUS_SMALL if reach <= 8 else (14 if reach <= 14 else 24)
 
 
 def adaptive_state(height, width, head=False, device=None):

@@ -212,9 +212,9 @@ def test_suggest_tile_radius(dev):
     import artemis_amd
     oy = torch.randn(1, 25, 16, 64, device=dev)
     ox = torch.randn(1, 25, 16, 64, device=dev)
-    assert artemis_amd.suggest_tile_radius(oy, ox) == 8      # N(0, 1): every whole-pixel offset within 8
+    assert artemis_amd.suggest_tile_radius(oy, ox) == -3     # N(0, 1): every whole-pixel offset within 8: the lean shape
     oy[0, 7, 3, 3] = 8.9
-    assert artemis_amd.suggest_tile_radius(oy, ox) == 8
+    assert artemis_amd.suggest_tile_radius(oy, ox) == -3
     oy[0, 7, 3, 3] = 14.9
     assert artemis_amd.suggest_tile_radius(oy, ox) == 14
     oy[0, 7, 3, 3] = -15.0
