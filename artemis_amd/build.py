@@ -34,7 +34,7 @@ def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [SRC, TILES_SRC, DEVICE_HDR, os.path.join(INCLUDE, "artemis_synth.h")]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INCLUDE, "artemis_synth.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
