@@ -647,19 +647,20 @@ static int run_backward(const Geom &g, int rc, const void *input_any, const floa
     // (synth_gin_gather.hpp).  Whether they do is found out on the device, by the gather kernel itself:
     // it and the scatter kernels are both enqueued, and the scatter kernels (`guarded`) leave at once
     // unless the gather kernel gave up.
+    if (need && (!workspace || workspace_bytes < need))
+        return fail(hipErrorInvalidValue,
+                    "artemis_synth_backward: grad_input needs %zu workspace bytes "
+                    "(artemis_synth_backward_workspace_bytes), got %zu", need,
+                    workspace ? workspace_bytes : (size_t)0);
+    if (need && ((uintptr_t)workspace & 15) != 0)
+        return fail(hipErrorInvalidValue, "artemis_synth_backward: workspace not 16-byte aligned");
     GatherPlan plan;
     GatherTry gtry{false, 0ull, nullptr};
+    // (asked only once the call is known to go ahead: an attempt counts in the back-off)
     if (grad_input && Rg > 0 && need && g_gin_gather.load(std::memory_order_relaxed) && gather_plan(g, plan))
         gtry = gather_begin();
     const int guarded = gtry.attempt ? 1 : 0;
     if (grad_input) {
-        if (need && (!workspace || workspace_bytes < need))
-            return fail(hipErrorInvalidValue,
-                        "artemis_synth_backward: grad_input needs %zu workspace bytes "
-                        "(artemis_synth_backward_workspace_bytes), got %zu", need,
-                        workspace ? workspace_bytes : (size_t)0);
-        if (need && ((uintptr_t)workspace & 15) != 0)
-            return fail(hipErrorInvalidValue, "artemis_synth_backward: workspace not 16-byte aligned");
         hipError_t e = hipSuccess;
         // (with the gather kernel in front, the int64 image and gradInput are cleared only if the
         // scatter kernels get to run: zero_if_scatter_kernel below)
