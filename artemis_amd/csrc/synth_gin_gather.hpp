@@ -20,16 +20,21 @@
 // 1080p frame), and the host, told through pinned memory, enqueues the kernel only once in a while
 // as long as that goes on (gather_begin in synth_kernels.hip).
 //
-// Layout: a workgroup owns 64 WX x 4 (8 / WX) virtual texels (8 waves, 4 rows each; a lane is a column;
-// WX = 2: 128 x 16, WX = 1: 64 x 32 for narrow frames), stages gradOut for the pixels those can
-// receive from (zero outside the image) in LDS as float4 and walks the taps in the outer loop like
-// the other kernels: per tap a wave loads the tap's (w, a, b) for 5 pixel rows x 2 columns (s + dx),
-// 30 coalesced dword loads prefetched one tap ahead; pixel row i feeds texel row i - 1 through its
-// dy = 0 coefficients and texel row i through its dy = 1 ones.  The planes come about once from HBM
-// (the x - 1 column and the 5th row are L1 / L2 hits): 324 B per texel, the forward's traffic.
-// (Persistent workgroups taking tiles from per-XCD counters -- a 1080p frame is 1088 tiles for 768
-// resident workgroups, 1.4 rounds -- were tried and lost: 204 against 178 us.  Workgroups of 4 waves,
-// 128 x 8 texels, 1.7 rounds: 178 against 189 us at random init, but 8 us more to give up.)
+// Layout: a workgroup owns 63 WX x 4 (8 / WX) virtual texels (8 waves, 4 rows each; lanes 1..63 are
+// texel columns, lane 0 the column left of them; WX = 2: 126 x 16, WX = 1: 63 x 32 for narrow frames),
+// stages gradOut for the pixels those can receive from (zero outside the image) in LDS as float4 and
+// walks the taps in the outer loop like the other kernels: per tap a wave loads the tap's (w, a, b)
+// for 5 pixel rows at column x - s (the dx = 0 corner's pixel) -- 15 coalesced dword loads -- and takes
+// column x - s - 1 (dx = 1) from the lane to its left with a DPP wave shift, which is what lane 0 is
+// there for; pixel row i feeds texel row i - 1 through its dy = 0 coefficients and texel row i through
+// its dy = 1 ones.  The planes come about once from HBM (the 5th row and the lines shared with
+// neighbouring waves are L1 / L2 hits): 324 B per texel, the forward's traffic.
+// What the kernel's time did and did not depend on (1080p, random init): fetching both
+// columns with vector loads (30 per tap and wave) 188 us, one column 168 us; the tap loop in 25 basic blocks, which let the optimizer sink every
+// tap's loads to their first use (no tap fetched ahead), same time as one block with the rolling
+// refill below; 1, 2 or 3 workgroups per CU, two taps ahead, the window fill in one batch of loads,
+// half the arithmetic, no LDS reads: all within 3 us.  Non-temporal loads: +30 us.  Persistent
+// workgroups on per-XCD tile queues: +26 us.  4-wave workgroups: -6 % but 8 us more to give up.
 //
 // Clamping: a corner index is clamped to the frame, so the texels of the frame's border also collect
 // what falls on the VIRTUAL rows / columns outside it (one row and column past the padded frame in the
@@ -42,10 +47,11 @@
 #define ARTEMIS_SYNTH_GIN_GATHER_HPP
 
 constexpr int kGaRows = 4, kGaWaves = 8;
+constexpr int kGaCols = 63;  // texel columns of a wave: lanes 1..63; lane 0 fetches the column left of them
 constexpr int kGaMaxFold = 3;  // virtual rows / columns beyond a frame edge (<= kGaRows - 1)
 template <int WX>
 struct GaShape {
-    static constexpr int TX = 64 * WX, TY = kGaRows * (kGaWaves / WX);
+    static constexpr int TX = kGaCols * WX, TY = kGaRows * (kGaWaves / WX);
     static constexpr int LW = TX + 5, LH = TY + 5;
 };
 
@@ -70,7 +76,7 @@ inline bool gather_plan(const Geom &g, GatherPlan &p)
     if (p.ry1 - (g.Hin - 1) > kGaMaxFold || p.rx1 - (g.Win - 1) > kGaMaxFold) return false;
     const int nr = p.ry1 - p.ry0 + 1, nc = p.rx1 - p.rx0 + 1;
     p.wx = nc >= GaShape<2>::TX ? 2 : 1;
-    const int ty = p.wx == 2 ? GaShape<2>::TY : GaShape<1>::TY, tx = 64 * p.wx;
+    const int ty = p.wx == 2 ? GaShape<2>::TY : GaShape<1>::TY, tx = kGaCols * p.wx;
     if (nr < ty || nc < tx) return false;
     p.tiles_y = (nr + ty - 1) / ty;
     p.tiles_x = (nc + tx - 1) / tx;
@@ -78,13 +84,17 @@ inline bool gather_plan(const Geom &g, GatherPlan &p)
     return true;
 }
 
-// One tap's operands for 5 pixel rows, columns x - s (A) and x - s - 1 (B).  (Fetching only A and
-// taking B from the neighbouring lane through a DPP shift, lane 0's B through scalar loads, halves
-// the vector loads and was no faster: 188 against 178 us.)
+// One tap's operands for 5 pixel rows at column x - s.
 struct GaTap {
     float wA[kGaRows + 1], aA[kGaRows + 1], bA[kGaRows + 1];
-    float wB[kGaRows + 1], aB[kGaRows + 1], bB[kGaRows + 1];
 };
+
+// the value of the lane to the left (lane 0: 0): column x - s - 1 from the loads of column x - s
+__device__ __forceinline__ float ga_left(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138 /* wave_shr:1 */,
+                                                                 0xf, 0xf, true));
+}
 
 template <int WX>
 __global__ __launch_bounds__(64 * kGaWaves) void synth_gin_gather(
@@ -110,8 +120,8 @@ __global__ __launch_bounds__(64 * kGaWaves) void synth_gin_gather(
         const int rs = min(p.ry0 + TY * ty, p.ry1 - (TY - 1));  // the last tile ends at the last row
         const int xs = min(p.rx0 + TX * tx, p.rx1 - (TX - 1));
         const int f0 = rs + kGaRows * wyv;  // the wave's first (virtual) texel row
-        const int xw = xs + 64 * wxv;       // the wave's first (virtual) texel column
-        const int vx = xw + l;              // the lane's
+        const int xw = xs + kGaCols * wxv;  // the wave's first (virtual) texel column: lane 1's
+        const int vx = xw + l - 1;          // the lane's (lane 0: the column left of the wave's)
         const int yb = f0 - g.oy0;          // pixel row of texel row f0 for r = 0, dy = 0
         const int xb = vx - g.ox0;          // pixel column for s = 0, dx = 0
         // A wave none of whose texels can receive anything (row strips: the frame's rows far from
@@ -120,20 +130,19 @@ __global__ __launch_bounds__(64 * kGaWaves) void synth_gin_gather(
         const float *wb = w + (size_t)n * 25 * plane, *ab = oy + (size_t)n * 25 * plane,
                     *bb = ox + (size_t)n * 25 * plane;
 
-        auto load_tap = [&](GaTap &c, int tap) {
+        auto load_row = [&](GaTap &c, int tap, int i) {
             const int r = tap / 5, s = tap - r * 5;
-            const unsigned xa = (unsigned)clampi(xb - s, 0, g.W - 1), xc = (unsigned)clampi(xb - s - 1, 0, g.W - 1);
-            const size_t pb = (size_t)tap * plane;
+            const unsigned xa = (unsigned)clampi(xb - s, 0, g.W - 1);
+            const size_t ro = (size_t)tap * plane + (size_t)clampi(yb - r - 1 + i, 0, g.H - 1) * g.W;  // wave-uniform
+            // (plain loads: the rows a wave shares with the wave above and the lines it shares with
+            // its neighbours come from L1 / L2; non-temporal loads cost 30 us)
+            c.wA[i] = (wb + ro)[xa];
+            c.aA[i] = (ab + ro)[xa];
+            c.bA[i] = (bb + ro)[xa];
+        };
+        auto load_tap = [&](GaTap &c, int tap) {
 #pragma unroll
-            for (int i = 0; i <= kGaRows; ++i) {
-                const size_t ro = pb + (size_t)clampi(yb - r - 1 + i, 0, g.H - 1) * g.W;  // wave-uniform
-                c.wA[i] = (wb + ro)[xa];
-                c.aA[i] = (ab + ro)[xa];
-                c.bA[i] = (bb + ro)[xa];
-                c.wB[i] = (wb + ro)[xc];
-                c.aB[i] = (ab + ro)[xc];
-                c.bB[i] = (bb + ro)[xc];
-            }
+            for (int i = 0; i <= kGaRows; ++i) load_row(c, tap, i);
         };
 
         // Is this the gather kernel's call at all?  Before anything is staged, every wave looks at
@@ -194,16 +203,20 @@ __global__ __launch_bounds__(64 * kGaWaves) void synth_gin_gather(
         if (live) {
             const lds_f32x4 *lwin =
                 (const lds_f32x4 *)((const __attribute__((address_space(3))) char *)(const lds_f32x4 *)win +
-                                    ((kGaRows * wyv) * LW + 64 * wxv + l) * 16);
+                                    ((kGaRows * wyv) * LW + kGaCols * wxv + max(l - 1, 0)) * 16);
+            // The 25 taps are ONE basic block: no branch, no store, one give-up test after the last.
+            // (With a test after every tap the optimizer sank each tap's loads out of the block that
+            // issues them into the block that uses them, so that no tap was fetched ahead.  The first
+            // tap's offsets were checked above; what only a later tap reveals costs this workgroup its
+            // 25 taps and nothing else.)
+            unsigned big = 0u;  // largest |offset| of the A columns, as a bit pattern (NaN above all)
+            // Fetching ahead is row by row: as soon as a pixel row's operands have been used, its
+            // registers receive the same row of the next tap, so one tap's worth of loads is always
+            // in flight in 15 registers, not 30 (73 VGPRs: three workgroups per CU).
             static_for<0, 25>([&](auto tc) {
                 constexpr int tap = decltype(tc)::value;
                 constexpr int r = tap / 5, s = tap % 5;
-                if (gave_up) return;  // wave-uniform
-                GaTap nxt;
-                if (tap < 24) load_tap(nxt, tap + 1);
-                __builtin_amdgcn_sched_barrier(0);
                 const bool okA = (unsigned)(xb - s) < (unsigned)g.W, okB = (unsigned)(xb - s - 1) < (unsigned)g.W;
-                unsigned big = 0u;  // largest |offset| of this tap's A column, as a bit pattern (NaN above all)
                 static_for<0, kGaRows + 1>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
                     const bool rowok = (unsigned)(yb - r - 1 + i) < (unsigned)g.H;  // wave-uniform
@@ -211,7 +224,10 @@ __global__ __launch_bounds__(64 * kGaWaves) void synth_gin_gather(
                     // a pixel outside the image contributes nothing: selects, so that whatever sits at
                     // the clamped address (Inf, NaN) cannot reach a texel the reference leaves finite
                     const float wA = vA ? cur.wA[i] : 0.f, aA = vA ? cur.aA[i] : 0.f, bA = vA ? cur.bA[i] : 0.f;
-                    const float wB = vB ? cur.wB[i] : 0.f, aB = vB ? cur.aB[i] : 0.f, bB = vB ? cur.bB[i] : 0.f;
+                    // (shifted first, selected afterwards: a DPP move is convergent and would turn a
+                    // conditional into a branch)
+                    const float wL = ga_left(cur.wA[i]), aL = ga_left(cur.aA[i]), bL = ga_left(cur.bA[i]);
+                    const float wB = vB ? wL : 0.f, aB = vB ? aL : 0.f, bB = vB ? bL : 0.f;
                     // (every (pixel, tap) is some texel's A column, so checking that column checks all)
                     big = max(big, max(absbits(aA), absbits(bA)));
                     // trunc = 0: the fractions are the offsets themselves.  Column x - s is this texel's
@@ -232,16 +248,19 @@ __global__ __launch_bounds__(64 * kGaWaves) void synth_gin_gather(
                         acc[i][1] += a1 * gA.y + b1 * gB.y;
                         acc[i][2] += a1 * gA.z + b1 * gB.z;
                     }
-                });
+                    // pin this row's arithmetic above, the refill below (else the scheduler hoists
+                    // every refill to the top of the block and both taps' operands are live at once)
 #pragma unroll
-                for (int j = 0; j < kGaRows; ++j) asm volatile("" : "+v"(acc[j][0]), "+v"(acc[j][1]), "+v"(acc[j][2]));
-                __builtin_amdgcn_sched_barrier(0);
-                if (__ballot(big >= kOneBits)) {  // an offset that does not truncate to zero: not this kernel's call
-                    if (l == 0) __hip_atomic_store(flag, kOneBits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    gave_up = true;
-                }
-                cur = nxt;
+                    for (int j = 0; j < kGaRows; ++j) asm volatile("" : "+v"(acc[j][0]), "+v"(acc[j][1]), "+v"(acc[j][2]));
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (tap < 24) load_row(cur, tap + 1, i);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
             });
+            if (__ballot(big >= kOneBits)) {  // an offset that does not truncate to zero: not this kernel's call
+                if (l == 0) __hip_atomic_store(flag, kOneBits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                gave_up = true;
+            }
 
             // Virtual rows above the frame fold onto row 0, those below it onto the last row
             // (wave-uniform, border waves only); fixed order.
@@ -270,7 +289,7 @@ __global__ __launch_bounds__(64 * kGaWaves) void synth_gin_gather(
             // ... and virtual columns left / right of the frame onto its first / last column (the
             // lanes in question sit in this wave: the first tile starts at rx0, the last ends at rx1)
             if (xw < 0) {  // wave-uniform
-                const int l0 = -xw;
+                const int l0 = 1 - xw;  // the lane of column 0; columns xw .. -1 sit in lanes 1 .. l0 - 1
 #pragma unroll
                 for (int j = 0; j < kGaRows; ++j)
 #pragma unroll
@@ -280,13 +299,13 @@ __global__ __launch_bounds__(64 * kGaWaves) void synth_gin_gather(
 #pragma unroll
                         for (int q = 1; q <= kGaMaxFold; ++q) {
                             const float o = __shfl_up(v, q);
-                            sum = (l == l0 && q <= l0) ? sum + o : sum;
+                            sum = (l == l0 && q <= l0 - 1) ? sum + o : sum;
                         }
                         acc[j][c] = sum;
                     }
             }
-            if (xw + 63 > g.Win - 1) {
-                const int lb = g.Win - 1 - xw;
+            if (xw + kGaCols - 1 > g.Win - 1) {
+                const int lb = g.Win - xw;  // the lane of the last column
 #pragma unroll
                 for (int j = 0; j < kGaRows; ++j)
 #pragma unroll
@@ -307,8 +326,8 @@ __global__ __launch_bounds__(64 * kGaWaves) void synth_gin_gather(
         // tile's first wave / lanes, the last tile's last -- other texels by every wave that computes
         // them (overlapping tiles: the same sum in the same order).  (A wave that gave up stores
         // nothing: the scatter kernels rewrite all of gradInput.)
-        const bool col_ok = vx >= 0 && vx <= g.Win - 1 && (vx != 0 || p.rx0 == 0 || xw == p.rx0) &&
-                            (vx != g.Win - 1 || p.rx1 == g.Win - 1 || xw + 63 == p.rx1);
+        const bool col_ok = l >= 1 && vx >= 0 && vx <= g.Win - 1 && (vx != 0 || p.rx0 == 0 || xw == p.rx0) &&
+                            (vx != g.Win - 1 || p.rx1 == g.Win - 1 || xw + kGaCols - 1 == p.rx1);
         float *gp = gin + (size_t)n * 3 * iplane;
 #pragma unroll
         for (int j = 0; j < kGaRows; ++j) {
