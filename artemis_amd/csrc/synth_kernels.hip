@@ -499,6 +499,13 @@ struct GatherTry {
 
 constexpr size_t asynth_header_bytes() { return kDetHeaderBytes; }
 
+// forget the back-off, and whatever reports of attempts issued so far are still on their way
+void gather_forget(AutoDevice *d)
+{
+    d->ga_skip = d->ga_backoff = d->ga_quiet = 0;
+    d->ga_seen = d->ga_seq;
+}
+
 GatherTry gather_begin()
 {
     GatherTry t{true, 0ull, nullptr};
@@ -976,7 +983,7 @@ void artemis_synth_auto_reset(void)
     std::lock_guard<std::mutex> lock(g_auto_mutex);
     if (AutoDevice *d = auto_device(false)) {
         for (int i = 0; i < kAutoKeys; ++i) d->e[i].used = false;
-        d->ga_skip = d->ga_backoff = d->ga_quiet = 0;
+        gather_forget(d);
     }
 }
 
@@ -985,7 +992,7 @@ int artemis_synth_set_gin_gather(int enable)
     if (enable < 0) return g_gin_gather.load(std::memory_order_relaxed);
     {  // (a change of the setting also forgets the current device's back-off: the next call tries)
         std::lock_guard<std::mutex> lock(g_auto_mutex);
-        if (AutoDevice *d = auto_device(false)) d->ga_skip = d->ga_backoff = d->ga_quiet = 0;
+        if (AutoDevice *d = auto_device(false)) gather_forget(d);
     }
     return g_gin_gather.exchange(enable ? 1 : 0, std::memory_order_relaxed);
 }

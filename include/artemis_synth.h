@@ -253,12 +253,12 @@ int artemis_synth_auto_query(int H, int W, int head, int *radius, double *frac8,
 void artemis_synth_auto_reset(void);
 
 /* gradInput in gather form.  When artemis_synth_backward* is asked for grad_input (k = 5, d = 1, C = 3,
- * tile_radius != NONE, a frame of at least 32 x 64 texels whose origin lies at most 3 rows / columns
+ * tile_radius != NONE, a frame of at least 32 x 63 texels whose origin lies at most 3 rows / columns
  * outside it) and every offset truncates to zero -- |offset| < 1 everywhere: a freshly initialised
  * model -- grad_input is summed per texel in registers in a fixed order instead of scattered through
  * atomics: bit-reproducible in either gin_mode and faster.  Whether the offsets
  * qualify is found out on the device: the gather kernel runs first, checks every offset it loads and
- * gives up at the first that reaches 1 (raising word 2 of the workspace header, which is 0 after a
+ * gives up if one reaches 1 (raising word 2 of the workspace header, which is 0 after a
  * call that the gather kernel completed); the scatter kernels are enqueued behind it and leave at
  * once unless it gave up.  No host synchronisation.  Giving up costs 13-18 us per 1080p frame; the
  * kernel's first workgroup reports it through the pinned record of ARTEMIS_SYNTH_RADIUS_AUTO (when a
