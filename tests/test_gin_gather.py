@@ -179,7 +179,11 @@ def test_give_ups_make_the_library_skip_the_kernel_for_a_while(lib, oracle):
     with artemis_amd.synth_options(tile_radius=_lib.RADIUS_AUTO):
         artemis_amd.FunctionSynth.apply(*t, 1)        # sets the record up
     torch.cuda.synchronize()
-    lib.artemis_synth_set_gin_gather(1)               # forget earlier tests' back-off
+    # a give-up whose report nobody has looked at yet must not count after the reset below
+    # (whatever ran before this test: the reset forgets reports of attempts already issued)
+    lib.artemis_synth_set_gin_gather(1)
+    assert backward_ex(lib, inp, w, oy, ox, gout, (0, 0), 1, reset_backoff=False)[2]
+    lib.artemis_synth_set_gin_gather(1)               # forget earlier back-off and pending reports
     tried = []
     for _ in range(8):
         gin, _, gave_up = backward_ex(lib, inp, w, oy, ox, gout, (0, 0), 1, reset_backoff=False)
