@@ -102,6 +102,22 @@ __global__ __launch_bounds__(256) void write1(float *__restrict__ dst, size_t n)
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) { if (NT) __builtin_nontemporal_store(1.5f, dst + i); else dst[i] = 1.5f; }
 }
 
+// each block copies ONE contiguous chunk (n / gridDim.x elements), 8 independent dword loads per thread
+// in flight: the shape of a tile-owning workgroup, as opposed to the grid-stride kernels above
+template <bool NT>
+__global__ __launch_bounds__(256) void copy1_chunk(const float *__restrict__ src, float *__restrict__ dst, size_t n)
+{
+    const size_t chunk = (n / gridDim.x) / 2048 * 2048;  // multiple of 8 x 256 elements
+    const size_t base = (size_t)blockIdx.x * chunk;
+    for (size_t i = base + threadIdx.x; i < base + chunk; i += 2048) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = NT ? __builtin_nontemporal_load(src + i + u * 256) : src[i + u * 256];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { if (NT) __builtin_nontemporal_store(v[u], dst + i + u * 256); else dst[i + u * 256] = v[u]; }
+    }
+}
+
 // variant encodes kernel; nbytes = size of the stream
 extern "C" int bw_run(int variant, const void *src, void *dst, size_t nbytes, int blocks, void *stream)
 {
@@ -122,6 +138,8 @@ extern "C" int bw_run(int variant, const void *src, void *dst, size_t nbytes, in
     case 11: hipLaunchKernelGGL((copy1_nt<8, true, true>), dim3(blocks), dim3(256), 0, st, (const float *)src, (float *)dst, n1); break;
     case 12: hipLaunchKernelGGL((write1<false>), dim3(blocks), dim3(256), 0, st, (float *)dst, n1); break;
     case 13: hipLaunchKernelGGL((write1<true>), dim3(blocks), dim3(256), 0, st, (float *)dst, n1); break;
+    case 14: hipLaunchKernelGGL((copy1_chunk<false>), dim3(blocks), dim3(256), 0, st, (const float *)src, (float *)dst, n1); break;
+    case 15: hipLaunchKernelGGL((copy1_chunk<true>), dim3(blocks), dim3(256), 0, st, (const float *)src, (float *)dst, n1); break;
     default: return -1;
     }
     return (int)hipGetLastError();
