@@ -733,6 +733,91 @@ __global__ __launch_bounds__(256) void stream_tapsync(const float *__restrict__ 
         }
     }
 }
+// The same with one pace counter per XCD (workgroup id % 8): atomics and loads of workgroups on one
+// XCD meet in that XCD's L2.  D >= 2 (a wave's own tap t is counted only after the wait of tap t).
+#ifndef PACE_SCOPE
+#define PACE_SCOPE __HIP_MEMORY_SCOPE_AGENT
+#endif
+__device__ unsigned g_progx[8 * 64 * 25];
+__global__ void zero_progx() { for (int i = threadIdx.x; i < 8 * 64 * 25; i += blockDim.x) g_progx[i] = 0; }
+template <int LDSB, int TH, int D, int SPINS>
+__global__ __launch_bounds__(256) void stream_tapsync_xcd(const float *__restrict__ w, const float *__restrict__ oy,
+                                                const float *__restrict__ ox, float *__restrict__ gw,
+                                                float *__restrict__ ga, float *__restrict__ gb,
+                                                int H, int W)
+{
+    __shared__ float dummy[LDSB / 4];
+    if (LDSB > 4 && threadIdx.x == 999) dummy[threadIdx.y] = 0;
+    const int wy = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int tiles_x = (W + 63) / 64, tiles_y = (H + TH - 1) / TH, ntiles = tiles_x * tiles_y;
+    const size_t plane = (size_t)H * W;
+    constexpr int ROWS = TH / 4;
+    const int G = gridDim.x, xcd = blockIdx.x & 7, per = (ntiles + 7) / 8;
+    unsigned *prog = g_progx + xcd * 64 * 25;
+    // XCD i takes the i-th band of tiles, as the product kernels do
+#pragma unroll 1
+    for (int iter = 0, j = blockIdx.x >> 3; j < per; ++iter, j += G / 8) {
+        const int tile = xcd * per + j;
+        if (tile >= ntiles) break;
+        const int left = min(per, ntiles - xcd * per) - iter * (G / 8);  // this XCD's workgroups in this iteration
+        const unsigned expected = 4u * (unsigned)min(G / 8, left);
+        const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+        const int tx0 = txi * 64, ty0 = tyi * TH;
+        const unsigned x = min(tx0 + (int)threadIdx.x, W - 1);
+        float buf[2][3 * ROWS];
+        auto issue = [&](int t, float *dst) {
+#pragma unroll
+            for (int jj = 0; jj < ROWS; ++jj) {
+                const int y = min(ty0 + wy + 4 * jj, H - 1);
+                const size_t o = (size_t)y * W + (size_t)t * plane;
+                dst[3 * jj] = __builtin_nontemporal_load(w + o + x);
+                dst[3 * jj + 1] = __builtin_nontemporal_load(oy + o + x);
+                dst[3 * jj + 2] = __builtin_nontemporal_load(ox + o + x);
+            }
+        };
+        issue(0, buf[0]);
+#pragma unroll
+        for (int t = 0; t < 25; ++t) {
+            if (t + 1 < 25) {
+                if (D > 0 && t + 1 - D >= 0) {
+                    const unsigned *slot = &prog[(iter & 63) * 25 + t + 1 - D];
+                    int spins = 0;
+                    while (__hip_atomic_load(slot, __ATOMIC_RELAXED, PACE_SCOPE) < expected && ++spins < SPINS)
+                        __builtin_amdgcn_s_sleep(2);
+                    if (spins >= SPINS && (threadIdx.x & 63) == 0) atomicAdd(&g_progx[8 * 64 * 25 - 1], 1u);  // timeouts
+                }
+                issue(t + 1, buf[(t + 1) & 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            float *c = buf[t & 1];
+#pragma unroll
+            for (int jj = 0; jj < ROWS; ++jj) {
+                const int y = min(ty0 + wy + 4 * jj, H - 1);
+                const size_t o = (size_t)y * W + (size_t)t * plane;
+                const float v0 = c[3 * jj] * 1.5f, v1 = c[3 * jj + 1] + c[3 * jj], v2 = c[3 * jj + 2] - c[3 * jj];
+                __builtin_nontemporal_store(v0, gw + o + x);
+                __builtin_nontemporal_store(v1, ga + o + x);
+                __builtin_nontemporal_store(v2, gb + o + x);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (D > 0 && (threadIdx.x & 63) == 0)
+                __hip_atomic_fetch_add(&prog[(iter & 63) * 25 + t], 1u, __ATOMIC_RELAXED, PACE_SCOPE);
+        }
+    }
+}
+extern "C" unsigned exp_pace_timeouts()
+{
+    unsigned v = 0;
+    hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_progx), 4, (8 * 64 * 25 - 1) * 4);
+    return v;
+}
+template <int LDSB, int TH, int D, int SPINS>
+static void ltx(int G, const float *w, const float *oy, const float *ox, float *gw, float *ga, float *gb, int H, int W, hipStream_t st)
+{
+    hipLaunchKernelGGL(zero_progx, dim3(1), dim3(256), 0, st);
+    hipLaunchKernelGGL((stream_tapsync_xcd<LDSB, TH, D, SPINS>), dim3(G), dim3(64, 4), 0, st, w, oy, ox, gw, ga, gb, H, W);
+}
+
 template <int LDSB, int TH, bool BWD, int D>
 static void lts(int G, const float *w, const float *oy, const float *ox, float *gw, float *ga, float *gb, int H, int W, hipStream_t st)
 {
@@ -800,6 +885,15 @@ extern "C" int exp_runb(int variant, const float *w, const float *oy, const floa
     case 56: lts<70000, 32, false, 2>(512, w, oy, ox, gw, ga, gb, H, W, st); break;
     case 57: lts<36000, 32, true, 2>(1024, w, oy, ox, gw, ga, gb, H, W, st); break;
     case 58: lts<36000, 32, true, 0>(1024, w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 200: ltx<70000, 32, 0, 1>(512, w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 201: ltx<70000, 32, 2, 400>(512, w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 202: ltx<70000, 32, 3, 400>(512, w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 203: ltx<70000, 32, 4, 400>(512, w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 204: ltx<140000, 32, 0, 1>(256, w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 205: ltx<140000, 32, 2, 400>(256, w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 206: ltx<140000, 32, 3, 400>(256, w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 207: ltx<140000, 16, 2, 400>(256, w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 208: ltx<140000, 16, 0, 1>(256, w, oy, ox, gw, ga, gb, H, W, st); break;
     case 107: ltmw<88000, 4, false>(w, oy, ox, gw, ga, gb, H, W, st); break;
     case 108: ltmw<140000, 4, false>(w, oy, ox, gw, ga, gb, H, W, st); break;
     case 109: ltmw<140000, 4, true>(w, oy, ox, gw, ga, gb, H, W, st); break;

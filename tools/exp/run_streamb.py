@@ -3,7 +3,7 @@ import ctypes, os, statistics, sys
 import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-lib = ctypes.CDLL(os.path.join(ROOT, "artemis_amd", "lib", "exp", "libexp_stream.so"))
+lib = ctypes.CDLL(os.environ.get("EXP_STREAM_LIB", os.path.join(ROOT, "artemis_amd", "lib", "exp", "libexp_stream.so")))
 lib.exp_runb.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 6 + [ctypes.c_int] * 2 + [ctypes.c_void_p]
 dev = torch.device("cuda:0")
 H, W = 1080, 1920
@@ -21,4 +21,7 @@ for rnd in range(9):
 for v in variants:
     med = statistics.median(T[v])
     nb = 300.0 if v in (90, 91, 92) else 312.0 if v in (35,36,37,38,39,44,45,46,54,55,56,62,63,73,74,83,97,107,108,110) else 600.0
+    if hasattr(lib, "exp_pace_timeouts") and v >= 200:
+        lib.exp_runb(v, *[t.data_ptr() for t in sets[0]], H, W, st); torch.cuda.synchronize()
+        print(f"   (pace waits that ran into their bound in one launch: {lib.exp_pace_timeouts()})")
     print(f"stream variant {v:2d}: {med*1e3:8.1f} us (min {min(T[v])*1e3:8.1f}) {nb*H*W/med/1e6:7.0f} GB/s")
