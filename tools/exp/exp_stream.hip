@@ -818,6 +818,76 @@ static void ltx(int G, const float *w, const float *oy, const float *ox, float *
     hipLaunchKernelGGL((stream_tapsync_xcd<LDSB, TH, D, SPINS>), dim3(G), dim3(64, 4), 0, st, w, oy, ox, gw, ga, gb, H, W);
 }
 
+// Pacing without communication: every workgroup holds tap t back until the chip-wide constant-rate
+// clock (wall_clock64, 100 MHz) reaches t0 + (25 * iteration + t) * ticks, t0 written by a one-thread
+// kernel in front.  Workgroups that are ahead wait, those behind never do.
+__device__ unsigned long long g_t0;
+__global__ void set_t0() { g_t0 = wall_clock64() + 300; }
+template <int LDSB, int TH>
+__global__ __launch_bounds__(256) void stream_clockpace(const float *__restrict__ w, const float *__restrict__ oy,
+                                                const float *__restrict__ ox, float *__restrict__ gw,
+                                                float *__restrict__ ga, float *__restrict__ gb,
+                                                int H, int W, int ticks)
+{
+    __shared__ float dummy[LDSB / 4];
+    if (LDSB > 4 && threadIdx.x == 999) dummy[threadIdx.y] = 0;
+    const int wy = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int tiles_x = (W + 63) / 64, tiles_y = (H + TH - 1) / TH, ntiles = tiles_x * tiles_y;
+    const size_t plane = (size_t)H * W;
+    constexpr int ROWS = TH / 4;
+    const int G = gridDim.x, xcd = blockIdx.x & 7, per = (ntiles + 7) / 8;
+    const unsigned long long t0 = __hip_atomic_load(&g_t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll 1
+    for (int iter = 0, j = blockIdx.x >> 3; j < per; ++iter, j += G / 8) {
+        const int tile = xcd * per + j;
+        if (tile >= ntiles) break;
+        const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+        const int tx0 = txi * 64, ty0 = tyi * TH;
+        const unsigned x = min(tx0 + (int)threadIdx.x, W - 1);
+        float buf[2][3 * ROWS];
+        auto issue = [&](int t, float *dst) {
+#pragma unroll
+            for (int jj = 0; jj < ROWS; ++jj) {
+                const int y = min(ty0 + wy + 4 * jj, H - 1);
+                const size_t o = (size_t)y * W + (size_t)t * plane;
+                dst[3 * jj] = __builtin_nontemporal_load(w + o + x);
+                dst[3 * jj + 1] = __builtin_nontemporal_load(oy + o + x);
+                dst[3 * jj + 2] = __builtin_nontemporal_load(ox + o + x);
+            }
+        };
+        issue(0, buf[0]);
+#pragma unroll
+        for (int t = 0; t < 25; ++t) {
+            if (t + 1 < 25) {
+                if (ticks > 0) {
+                    const unsigned long long due = t0 + (unsigned long long)((25 * iter + t + 1) * ticks);
+                    int spins = 0;
+                    while (wall_clock64() < due && ++spins < 4000) __builtin_amdgcn_s_sleep(1);
+                }
+                issue(t + 1, buf[(t + 1) & 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            float *c = buf[t & 1];
+#pragma unroll
+            for (int jj = 0; jj < ROWS; ++jj) {
+                const int y = min(ty0 + wy + 4 * jj, H - 1);
+                const size_t o = (size_t)y * W + (size_t)t * plane;
+                const float v0 = c[3 * jj] * 1.5f, v1 = c[3 * jj + 1] + c[3 * jj], v2 = c[3 * jj + 2] - c[3 * jj];
+                __builtin_nontemporal_store(v0, gw + o + x);
+                __builtin_nontemporal_store(v1, ga + o + x);
+                __builtin_nontemporal_store(v2, gb + o + x);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+template <int LDSB, int TH>
+static void lcp(int G, int ticks, const float *w, const float *oy, const float *ox, float *gw, float *ga, float *gb, int H, int W, hipStream_t st)
+{
+    hipLaunchKernelGGL(set_t0, dim3(1), dim3(1), 0, st);
+    hipLaunchKernelGGL((stream_clockpace<LDSB, TH>), dim3(G), dim3(64, 4), 0, st, w, oy, ox, gw, ga, gb, H, W, ticks);
+}
+
 template <int LDSB, int TH, bool BWD, int D>
 static void lts(int G, const float *w, const float *oy, const float *ox, float *gw, float *ga, float *gb, int H, int W, hipStream_t st)
 {
@@ -885,6 +955,17 @@ extern "C" int exp_runb(int variant, const float *w, const float *oy, const floa
     case 56: lts<70000, 32, false, 2>(512, w, oy, ox, gw, ga, gb, H, W, st); break;
     case 57: lts<36000, 32, true, 2>(1024, w, oy, ox, gw, ga, gb, H, W, st); break;
     case 58: lts<36000, 32, true, 0>(1024, w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 300: lcp<140000, 32>(256, 0, w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 301: lcp<140000, 32>(256, 180, w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 302: lcp<140000, 32>(256, 200, w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 303: lcp<140000, 32>(256, 220, w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 304: lcp<140000, 32>(256, 240, w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 305: lcp<140000, 32>(256, 160, w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 310: lcp<70000, 32>(512, 0, w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 311: lcp<70000, 32>(512, 360, w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 312: lcp<70000, 32>(512, 400, w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 313: lcp<70000, 32>(512, 440, w, oy, ox, gw, ga, gb, H, W, st); break;
+    case 314: lcp<70000, 32>(512, 480, w, oy, ox, gw, ga, gb, H, W, st); break;
     case 200: ltx<70000, 32, 0, 1>(512, w, oy, ox, gw, ga, gb, H, W, st); break;
     case 201: ltx<70000, 32, 2, 400>(512, w, oy, ox, gw, ga, gb, H, W, st); break;
     case 202: ltx<70000, 32, 3, 400>(512, w, oy, ox, gw, ga, gb, H, W, st); break;
